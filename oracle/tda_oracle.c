@@ -1,0 +1,703 @@
+/*
+ * oracle/tda_oracle.c -- CPU restatement of the reference's per-window TDA hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under tda_eeg_audio_amd/ (the product) may
+ * import, link or call this file; only tests/, __graft_entry__.smoke() and the
+ * cpu_baseline leg of bench.py use it, and only as the checker / CPU timing leg.
+ *
+ * PARITY STATUS
+ *   * numpy-only stages (corr->dist, Takens, min-max normalise, tau, features,
+ *     window slicing) are PINNED by golden vectors captured from the reference's
+ *     own functions (tests/golden/make_golden.py).
+ *   * Rips H0/H1 and Wasserstein live in third-party wheels that are absent from
+ *     /root/reference and from this image: `ripser` (requirements.txt:5, ">=0.6",
+ *     unpinned) and `persim` (requirements.txt:6, ">=0.3", unpinned).  For those
+ *     two functions this oracle restates the PUBLISHED algorithms (U. Bauer,
+ *     "Ripser: efficient computation of Vietoris-Rips persistence barcodes",
+ *     JACT 2021: Z/2 persistent cohomology, clearing, emergent pairs, implicit
+ *     reduction with heap columns; persim.wasserstein: (M+N)x(M+N) assignment with
+ *     diagonal projections solved by shortest augmenting paths) and is anchored on
+ *     the reference's call sites (scripts/utils.py:131,140,189) -- there are no
+ *     golden vectors for them in the reference:  ** PARITY UNPINNED ** at the
+ *     ripser/persim boundary.  It is cross-checked against an independent
+ *     brute-force boundary-matrix reduction (oracle/brute.py), against scipy's
+ *     linear_sum_assignment and against closed-form known answers.
+ *
+ * Reference lines followed (paths relative to /root/reference):
+ *   notebooks/2_graph_construction.ipynb:86-122   corr -> distance
+ *   scripts/utils.py:82-89    create_windows
+ *   scripts/utils.py:92-104   compute_tau
+ *   scripts/utils.py:107-116  takens_embedding
+ *   scripts/utils.py:123-132  compute_audio_persistence
+ *   scripts/utils.py:135-141  compute_eeg_persistence
+ *   scripts/utils.py:144-177  extract_features
+ *   scripts/utils.py:180-191  safe_wasserstein
+ *
+ * Floating point: compiled with -ffp-contract=off; every fused multiply-add is an
+ * explicit fma() so that the HIP path can reproduce the exact operation order.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include <float.h>
+
+#define ORC_EXPORT __attribute__((visibility("default")))
+
+/* ------------------------------------------------------------------------- */
+/* corr -> distance  (nb2:86-122)                                            */
+/* ------------------------------------------------------------------------- */
+/*
+ * np.corrcoef(window): rows are variables.  X -= mean(row); c = X X^T; c *= 1/(T-1);
+ * d = diag(c); s = sqrt(d); c /= s[:,None]; c /= s[None,:]; clip to [-1,1]
+ * (nb2:88); NaN -> 0 (nb2:95).  Then clip (nb2:105), sqrt(2(1-r)) (nb2:108),
+ * max(.,0) (nb2:119), diag <- 0 (nb2:120).
+ *
+ * Operation order fixed here (and mirrored by the HIP kernel):
+ *   mean_i  = (sum_t x[i][t], sequential in t) / T
+ *   xc      = x - mean
+ *   c_ij    = fma chain over t = 0..T-1, accumulator starts at 0
+ *   c_ij   *= 1.0/(T-1)
+ *   r_ij    = (c_ij / s_i) / s_j
+ * numpy's BLAS/pairwise summation order differs in the last ulps; that difference
+ * is bounded in tests (<= 1e-12 abs), it cannot be made bit-exact on any other BLAS.
+ */
+ORC_EXPORT void orc_corr_dist(const double* win, int n_ch, int n_t,
+                              double* corr_out, double* dist_out)
+{
+    double* xc = (double*)malloc(sizeof(double) * (size_t)n_ch * n_t);
+    double* c = (double*)malloc(sizeof(double) * (size_t)n_ch * n_ch);
+    double* sd = (double*)malloc(sizeof(double) * (size_t)n_ch);
+    for (int i = 0; i < n_ch; ++i) {
+        double s = 0.0;
+        for (int t = 0; t < n_t; ++t) s += win[(size_t)i * n_t + t];
+        double m = s / (double)n_t;
+        for (int t = 0; t < n_t; ++t) xc[(size_t)i * n_t + t] = win[(size_t)i * n_t + t] - m;
+    }
+    const double fact = 1.0 / (double)(n_t - 1);
+    for (int i = 0; i < n_ch; ++i)
+        for (int j = 0; j <= i; ++j) {
+            double acc = 0.0;
+            for (int t = 0; t < n_t; ++t)
+                acc = fma(xc[(size_t)i * n_t + t], xc[(size_t)j * n_t + t], acc);
+            acc *= fact;
+            c[i * n_ch + j] = acc;
+            c[j * n_ch + i] = acc;
+        }
+    for (int i = 0; i < n_ch; ++i) sd[i] = sqrt(c[i * n_ch + i]);
+    for (int i = 0; i < n_ch; ++i)
+        for (int j = 0; j < n_ch; ++j) {
+            double r = (c[i * n_ch + j] / sd[i]) / sd[j];
+            if (r > 1.0) r = 1.0;            /* np.clip: NaN stays NaN */
+            if (r < -1.0) r = -1.0;
+            if (r != r) r = 0.0;             /* nan_to_num(nan=0.0), nb2:95 */
+            if (corr_out) corr_out[i * n_ch + j] = r;
+            double d = sqrt(2.0 * (1.0 - r));
+            if (!(d > 0.0)) d = 0.0;
+            if (i == j) d = 0.0;
+            if (dist_out) dist_out[i * n_ch + j] = d;
+        }
+    free(xc); free(c); free(sd);
+}
+
+/* ------------------------------------------------------------------------- */
+/* create_windows (utils:82-89), compute_tau (utils:92-104), takens (107-116) */
+/* ------------------------------------------------------------------------- */
+ORC_EXPORT int orc_count_windows(int len, int win, int step)
+{
+    int n = 0;
+    for (int start = 0; start + win <= len; start += step) ++n;
+    return n;
+}
+
+/* ac[k] = sum_t sc[t+k]*sc[t] as a sequential fma chain over t; only the sign of
+ * ac[k] matters (utils:100 divides by ac[0]+1e-10 > 0). */
+ORC_EXPORT int orc_compute_tau(const double* s, int len, int max_lag)
+{
+    if (max_lag < 0) max_lag = len / 4;          /* utils:94-95 (None) */
+    if (max_lag > len - 1) max_lag = len - 1;    /* utils:96 */
+    double sum = 0.0;
+    for (int t = 0; t < len; ++t) sum += s[t];
+    double m = sum / (double)len;
+    int lim = max_lag < len ? max_lag : len;     /* utils:101  min(max_lag, len(ac)) */
+    for (int k = 1; k < lim; ++k) {
+        double acc = 0.0;
+        for (int t = 0; t + k < len; ++t) acc = fma(s[t + k] - m, s[t] - m, acc);
+        if (acc <= 0.0) return k > 1 ? k : 1;
+    }
+    int d = max_lag / 10;
+    return d > 1 ? d : 1;
+}
+
+/* returns number of points P; pc_out is (P, dim) row-major */
+ORC_EXPORT int orc_takens(const double* s, int len, int dim, int tau, int subsample,
+                          double* pc_out)
+{
+    int n = len - (dim - 1) * tau;
+    if (n <= 0) return 0;
+    if (subsample < 1) subsample = 1;
+    int P = 0;
+    for (int i = 0; i < n; i += subsample) {
+        for (int k = 0; k < dim; ++k) pc_out[P * dim + k] = s[i + k * tau];
+        ++P;
+    }
+    return P;
+}
+
+/* utils:127-130  per-column min-max normalisation; zero range -> 1 */
+ORC_EXPORT void orc_minmax_normalise(const double* pc, int P, int dim, double* out)
+{
+    for (int k = 0; k < dim; ++k) {
+        double mn = pc[k], mx = pc[k];
+        for (int i = 1; i < P; ++i) {
+            double v = pc[i * dim + k];
+            if (v < mn) mn = v;
+            if (v > mx) mx = v;
+        }
+        double rg = mx - mn;
+        if (rg == 0.0) rg = 1.0;
+        for (int i = 0; i < P; ++i) out[i * dim + k] = (pc[i * dim + k] - mn) / rg;
+    }
+}
+
+/* ripser's point-cloud path = sklearn.metrics.pairwise_distances(X) (euclidean):
+ *   D2 = -2 X X^T ; D2 += |x_i|^2 ; D2 += |x_j|^2 ; max(D2,0) ; diag 0 ; sqrt.
+ * |x|^2 is einsum('ij,ij->i') = plain sequential multiply-add without fma;
+ * X X^T is a BLAS dgemm with K = dim (3): restated as fma(x2,y2,fma(x1,y1,x0*y0)).
+ * Differences to a particular BLAS are last-ulp in f64, i.e. below the float32
+ * rounding ripser applies next, except for values straddling a rounding boundary.
+ */
+ORC_EXPORT void orc_cloud_dm(const double* x, int P, int dim, double* dm)
+{
+    double* nn = (double*)malloc(sizeof(double) * (size_t)(P > 0 ? P : 1));
+    for (int i = 0; i < P; ++i) {
+        double s = 0.0;
+        for (int k = 0; k < dim; ++k) s += x[i * dim + k] * x[i * dim + k];
+        nn[i] = s;
+    }
+    for (int i = 0; i < P; ++i)
+        for (int j = 0; j < P; ++j) {
+            double dot = x[i * dim] * x[j * dim];
+            for (int k = 1; k < dim; ++k) dot = fma(x[i * dim + k], x[j * dim + k], dot);
+            double d2 = -2.0 * dot;
+            d2 += nn[i];
+            d2 += nn[j];
+            if (!(d2 > 0.0)) d2 = 0.0;
+            if (i == j) d2 = 0.0;
+            dm[i * P + j] = sqrt(d2);
+        }
+    free(nn);
+}
+
+/* ------------------------------------------------------------------------- */
+/* Vietoris-Rips H0/H1 persistence: restatement of the Ripser algorithm       */
+/* ------------------------------------------------------------------------- */
+typedef struct { float diam; int idx; int a, b; } ent_t;   /* a > b for edges */
+
+/* heap order: top = smallest diameter, ties -> largest index
+ * (ripser's greater_diameter_or_smaller_index used as priority_queue comparator) */
+static inline int ent_before(const ent_t* x, const ent_t* y)
+{
+    return x->diam < y->diam || (x->diam == y->diam && x->idx > y->idx);
+}
+
+typedef struct { ent_t* v; int n, cap; } heap_t;
+
+static void heap_push(heap_t* h, ent_t e)
+{
+    if (h->n == h->cap) {
+        h->cap = h->cap ? 2 * h->cap : 256;
+        h->v = (ent_t*)realloc(h->v, sizeof(ent_t) * (size_t)h->cap);
+    }
+    int i = h->n++;
+    while (i > 0) {
+        int p = (i - 1) >> 1;
+        if (!ent_before(&e, &h->v[p])) break;
+        h->v[i] = h->v[p];
+        i = p;
+    }
+    h->v[i] = e;
+}
+
+static ent_t heap_pop(heap_t* h)
+{
+    ent_t top = h->v[0];
+    ent_t last = h->v[--h->n];
+    int i = 0, n = h->n;
+    while (1) {
+        int l = 2 * i + 1, r = l + 1, m = i;
+        const ent_t* best = &last;
+        if (l < n && ent_before(&h->v[l], best)) { m = l; best = &h->v[l]; }
+        if (r < n && ent_before(&h->v[r], best)) { m = r; best = &h->v[r]; }
+        if (m == i) break;
+        h->v[i] = h->v[m];
+        i = m;
+    }
+    if (n > 0) h->v[i] = last;
+    return top;
+}
+
+/* Z/2: equal indices cancel in pairs */
+static int heap_pop_pivot(heap_t* h, ent_t* out)
+{
+    if (h->n == 0) return 0;
+    ent_t piv = heap_pop(h);
+    while (h->n > 0 && h->v[0].idx == piv.idx) {
+        heap_pop(h);
+        if (h->n == 0) return 0;
+        piv = heap_pop(h);
+    }
+    *out = piv;
+    return 1;
+}
+
+static int heap_get_pivot(heap_t* h, ent_t* out)
+{
+    if (!heap_pop_pivot(h, out)) return 0;
+    heap_push(h, *out);
+    return 1;
+}
+
+typedef struct {
+    int n;
+    const float* d;       /* full symmetric n x n float32 matrix */
+    float thresh;
+    int (*b3);            /* C(v,3) */
+} rips_t;
+
+static inline int c2(int v) { return v * (v - 1) / 2; }
+static inline int c3(int v) { return v * (v - 1) * (v - 2) / 6; }
+
+static inline float fmax3(float a, float b, float c)
+{
+    float m = a > b ? a : b;
+    return m > c ? m : c;
+}
+
+/* cofacet (triangle) of edge (a>b) with extra vertex v */
+static inline int tri_index(int a, int b, int v)
+{
+    if (v > a) return c3(v) + c2(a) + b;
+    if (v > b) return c3(a) + c2(v) + b;
+    return c3(a) + c2(b) + v;
+}
+
+typedef struct { int epoch; int col; } piv_slot_t;
+
+typedef struct {
+    ent_t* items;     /* concatenated reduction columns */
+    int n, cap;
+} redmat_t;
+
+static void push_coboundary(const rips_t* R, const ent_t* e, heap_t* wc)
+{
+    const int n = R->n, a = e->a, b = e->b;
+    const float* da = R->d + (size_t)a * n;
+    const float* db = R->d + (size_t)b * n;
+    for (int v = n - 1; v >= 0; --v) {
+        if (v == a || v == b) continue;
+        float dm = fmax3(e->diam, da[v], db[v]);
+        if (dm <= R->thresh) {
+            ent_t t = { dm, tri_index(a, b, v), 0, 0 };
+            heap_push(wc, t);
+        }
+    }
+}
+
+static int cmp_edge_asc(const void* x, const void* y)
+{
+    /* ascending diameter, ties: descending index (ripser's edge order for dim 0) */
+    const ent_t* p = (const ent_t*)x; const ent_t* q = (const ent_t*)y;
+    if (p->diam < q->diam) return -1;
+    if (p->diam > q->diam) return 1;
+    return (p->idx > q->idx) ? -1 : (p->idx < q->idx);
+}
+
+static int uf_find(int* parent, int x)
+{
+    int z = x;
+    while (parent[z] != z) z = parent[z];
+    while (parent[x] != z) { int y = parent[x]; parent[x] = z; x = y; }
+    return z;
+}
+
+/*
+ * dm_f32: full n x n symmetric float32 matrix (what ripser holds after its cast).
+ * Output rows are (birth, death) float32 pairs, +inf for essential classes.
+ *   H0: finite rows in ascending death order, then one (0,inf) per component.
+ *   H1: ripser's column order = descending birth.
+ * Returns 0, or 1 if h0_cap / h1_cap was too small (counts still report the need).
+ */
+ORC_EXPORT int orc_rips_f32(const float* dm_f32, int n, float thresh,
+                            float* h0, int h0_cap, int* n_h0,
+                            float* h1, int h1_cap, int* n_h1)
+{
+    int status = 0, k0 = 0, k1 = 0;
+    rips_t R = { n, dm_f32, thresh, 0 };
+    int ne = 0;
+    ent_t* edges = (ent_t*)malloc(sizeof(ent_t) * (size_t)(c2(n) + 1));
+    for (int a = 1; a < n; ++a)
+        for (int b = 0; b < a; ++b) {
+            float d = dm_f32[(size_t)a * n + b];
+            if (d <= thresh) { ent_t e = { d, c2(a) + b, a, b }; edges[ne++] = e; }
+        }
+    qsort(edges, (size_t)ne, sizeof(ent_t), cmp_edge_asc);
+
+    /* ---- dimension 0: Kruskal; non-merging edges become dim-1 columns ---- */
+    int* parent = (int*)malloc(sizeof(int) * (size_t)(n > 0 ? n : 1));
+    for (int i = 0; i < n; ++i) parent[i] = i;
+    ent_t* cols = (ent_t*)malloc(sizeof(ent_t) * (size_t)(ne + 1));
+    int ncols = 0, ncomp = n;
+    for (int i = 0; i < ne; ++i) {
+        int u = uf_find(parent, edges[i].a), v = uf_find(parent, edges[i].b);
+        if (u != v) {
+            if (edges[i].diam != 0.0f) {
+                if (k0 < h0_cap) { h0[2 * k0] = 0.0f; h0[2 * k0 + 1] = edges[i].diam; } else status = 1;
+                ++k0;
+            }
+            parent[u] = v;
+            --ncomp;
+        } else {
+            cols[ncols++] = edges[i];
+        }
+    }
+    for (int i = 0; i < ncomp; ++i) {
+        if (k0 < h0_cap) { h0[2 * k0] = 0.0f; h0[2 * k0 + 1] = INFINITY; } else status = 1;
+        ++k0;
+    }
+    /* reverse: descending diameter, ties ascending index */
+    for (int i = 0, j = ncols - 1; i < j; ++i, --j) { ent_t t = cols[i]; cols[i] = cols[j]; cols[j] = t; }
+
+    /* ---- dimension 1: cohomology reduction with clearing + emergent pairs ---- */
+    static __thread piv_slot_t* piv = 0;
+    static __thread int piv_cap = 0, epoch = 0;
+    int ntri = c3(n) + 1;
+    if (ntri > piv_cap) {
+        free(piv);
+        piv = (piv_slot_t*)calloc((size_t)ntri, sizeof(piv_slot_t));
+        piv_cap = ntri; epoch = 0;
+    }
+    ++epoch;
+    redmat_t RM = { 0, 0, 0 };
+    int* rm_start = (int*)malloc(sizeof(int) * (size_t)(ncols + 2));
+    heap_t wc = { 0, 0, 0 }, wr = { 0, 0, 0 };
+
+    for (int j = 0; j < ncols; ++j) {
+        rm_start[j] = RM.n;
+        const ent_t col = cols[j];
+        wc.n = 0; wr.n = 0;
+        ent_t pivot; int have = 0, emergent_done = 0;
+        {   /* init_coboundary_and_get_pivot with the emergent-pair shortcut */
+            int check = 1;
+            const int a = col.a, b = col.b;
+            const float* da = dm_f32 + (size_t)a * n;
+            const float* db = dm_f32 + (size_t)b * n;
+            for (int v = n - 1; v >= 0; --v) {
+                if (v == a || v == b) continue;
+                float dmx = fmax3(col.diam, da[v], db[v]);
+                if (dmx <= thresh) {
+                    ent_t t = { dmx, tri_index(a, b, v), 0, 0 };
+                    heap_push(&wc, t);
+                    if (check && dmx == col.diam) {
+                        if (piv[t.idx].epoch != epoch) { pivot = t; have = 1; emergent_done = 1; break; }
+                        check = 0;
+                    }
+                }
+            }
+            if (!emergent_done) have = heap_get_pivot(&wc, &pivot);
+        }
+        while (1) {
+            if (have) {
+                if (piv[pivot.idx].epoch == epoch) {
+                    int k = piv[pivot.idx].col;
+                    /* add column k: its own simplex plus its stored reduction column */
+                    heap_push(&wr, cols[k]);
+                    push_coboundary(&R, &cols[k], &wc);
+                    for (int q = rm_start[k]; q < rm_start[k + 1]; ++q) {
+                        heap_push(&wr, RM.items[q]);
+                        push_coboundary(&R, &RM.items[q], &wc);
+                    }
+                    have = heap_get_pivot(&wc, &pivot);
+                } else {
+                    if (pivot.diam > col.diam) {
+                        if (k1 < h1_cap) { h1[2 * k1] = col.diam; h1[2 * k1 + 1] = pivot.diam; } else status = 1;
+                        ++k1;
+                    }
+                    piv[pivot.idx].epoch = epoch;
+                    piv[pivot.idx].col = j;
+                    ent_t e;
+                    while (heap_pop_pivot(&wr, &e)) {
+                        if (RM.n == RM.cap) {
+                            RM.cap = RM.cap ? 2 * RM.cap : 1024;
+                            RM.items = (ent_t*)realloc(RM.items, sizeof(ent_t) * (size_t)RM.cap);
+                        }
+                        RM.items[RM.n++] = e;
+                    }
+                    break;
+                }
+            } else {
+                if (k1 < h1_cap) { h1[2 * k1] = col.diam; h1[2 * k1 + 1] = INFINITY; } else status = 1;
+                ++k1;
+                break;
+            }
+        }
+        rm_start[j + 1] = RM.n;
+    }
+    *n_h0 = k0; *n_h1 = k1;
+    free(edges); free(parent); free(cols); free(RM.items); free(rm_start); free(wc.v); free(wr.v);
+    return status;
+}
+
+/* compute_eeg_persistence pre-processing (utils:137-139) followed by ripser's
+ * float32 cast: dm = (D + D^T)/2, diag 0, max(.,0). */
+ORC_EXPORT void orc_eeg_prepare(const double* dist, int n, int symmetrise, float* dm_f32)
+{
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j < n; ++j) {
+            double v;
+            if (symmetrise) {
+                v = (dist[i * n + j] + dist[j * n + i]) / 2.0;
+                if (i == j) v = 0.0;
+                if (!(v > 0.0)) v = 0.0;       /* np.maximum(dm,0); NaN -> NaN in numpy, 0 here */
+            } else {
+                /* ripser.py reads dm[I > J] with xy-meshgrid = entries (i,j), i<j */
+                v = i < j ? dist[i * n + j] : (i > j ? dist[j * n + i] : 0.0);
+            }
+            dm_f32[i * n + j] = (float)v;
+        }
+}
+
+ORC_EXPORT int orc_rips_dm(const double* dist, int n, double thresh, int symmetrise,
+                           float* h0, int h0_cap, int* n_h0,
+                           float* h1, int h1_cap, int* n_h1)
+{
+    float* f = (float*)malloc(sizeof(float) * (size_t)(n * n + 1));
+    orc_eeg_prepare(dist, n, symmetrise, f);
+    int st = orc_rips_f32(f, n, (float)thresh, h0, h0_cap, n_h0, h1, h1_cap, n_h1);
+    free(f);
+    return st;
+}
+
+/* compute_audio_persistence (utils:123-132) from a raw window: Takens -> min-max
+ * -> pairwise -> float32 -> Rips.  P<3 -> the reference's [[0,0]],[[0,0]]. */
+ORC_EXPORT int orc_audio_persistence(const double* s, int len, int dim, int tau, int subsample,
+                                     double thresh, float* h0, int h0_cap, int* n_h0,
+                                     float* h1, int h1_cap, int* n_h1, int* n_points)
+{
+    int n = len - (dim - 1) * tau;
+    int Pmax = n > 0 ? (n + subsample - 1) / subsample : 0;
+    double* pc = (double*)malloc(sizeof(double) * (size_t)(Pmax * dim + 1));
+    int P = orc_takens(s, len, dim, tau, subsample, pc);
+    *n_points = P;
+    if (P < 3) {
+        h0[0] = 0; h0[1] = 0; *n_h0 = 1; h1[0] = 0; h1[1] = 0; *n_h1 = 1;
+        free(pc);
+        return 0;
+    }
+    double* pn = (double*)malloc(sizeof(double) * (size_t)(P * dim));
+    double* dm = (double*)malloc(sizeof(double) * (size_t)P * P);
+    float* f = (float*)malloc(sizeof(float) * (size_t)P * P);
+    orc_minmax_normalise(pc, P, dim, pn);
+    orc_cloud_dm(pn, P, dim, dm);
+    for (int i = 0; i < P * P; ++i) f[i] = (float)dm[i];
+    int st = orc_rips_f32(f, P, (float)thresh, h0, h0_cap, n_h0, h1, h1_cap, n_h1);
+    free(pc); free(pn); free(dm); free(f);
+    return st;
+}
+
+/* ------------------------------------------------------------------------- */
+/* extract_features (utils:144-177)                                          */
+/* ------------------------------------------------------------------------- */
+/* numpy's add.reduce uses pairwise summation with an 8-way unrolled base case
+ * for n >= 8 and blocks of 128; restated so that mean/std agree to the bit with
+ * np.mean/np.std/np.sum on contiguous float64 input. */
+static double np_pairwise_sum(const double* a, int n)
+{
+    if (n < 8) {
+        double res = 0.0;                       /* numpy: res = 0.; res += a[i] */
+        for (int i = 0; i < n; ++i) res += a[i];
+        return res;
+    } else if (n <= 128) {
+        double r[8];
+        for (int k = 0; k < 8; ++k) r[k] = a[k];
+        int i;
+        for (i = 8; i < n - (n % 8); i += 8)
+            for (int k = 0; k < 8; ++k) r[k] += a[i + k];
+        double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+        for (; i < n; ++i) res += a[i];
+        return res;
+    } else {
+        int n2 = n / 2;
+        n2 -= n2 % 8;
+        return np_pairwise_sum(a, n2) + np_pairwise_sum(a + n2, n - n2);
+    }
+}
+
+/* order: n_features, n_essential, mean_birth, std_birth, mean_death, std_death,
+ * mean_persistence, std_persistence, max_persistence, total_persistence,
+ * persistence_entropy  (utils:166-177) */
+ORC_EXPORT void orc_features(const double* dgm, int k, double* out)
+{
+    for (int i = 0; i < 11; ++i) out[i] = 0.0;
+    double* b = (double*)malloc(sizeof(double) * (size_t)(4 * (k > 0 ? k : 1)));
+    double* d = b + (k > 0 ? k : 1), *p = d + (k > 0 ? k : 1), *tmp = p + (k > 0 ? k : 1);
+    int m = 0, ness = 0;
+    for (int i = 0; i < k; ++i) {
+        double bi = dgm[2 * i], di = dgm[2 * i + 1];
+        if (isfinite(bi) && isfinite(di)) { b[m] = bi; d[m] = di; p[m] = di - bi; ++m; }
+        else ++ness;
+    }
+    out[1] = (double)ness;
+    if (m == 0) { free(b); return; }
+    out[0] = (double)m;
+    const double* arr[3] = { b, d, p };
+    for (int q = 0; q < 3; ++q) {
+        double mean = np_pairwise_sum(arr[q], m) / (double)m;
+        out[2 + 2 * q] = mean;
+        if (m > 1) {
+            /* np.std: sqrt(mean(abs(x - mean)**2)); x.mean via sum/n */
+            for (int i = 0; i < m; ++i) { double z = arr[q][i] - mean; tmp[i] = z * z; }
+            out[3 + 2 * q] = sqrt(np_pairwise_sum(tmp, m) / (double)m);
+        }
+    }
+    double mx = p[0];
+    for (int i = 1; i < m; ++i) if (p[i] > mx) mx = p[i];
+    out[8] = mx;
+    double tot = np_pairwise_sum(p, m);
+    out[9] = tot;
+    if (m > 1 && tot > 0.0) {
+        int c = 0;
+        for (int i = 0; i < m; ++i) {
+            double pn = p[i] / tot;
+            if (pn > 0.0) tmp[c++] = pn * log(pn + 1e-10);
+        }
+        out[10] = -np_pairwise_sum(tmp, c) / log((double)m + 1e-10);
+    }
+    free(b);
+}
+
+/* ------------------------------------------------------------------------- */
+/* persim.wasserstein restated  (called at utils:189)                        */
+/* ------------------------------------------------------------------------- */
+/* Rectangular/square linear sum assignment by shortest augmenting paths with
+ * dual variables (the algorithm class scipy.optimize.linear_sum_assignment uses).
+ * cost is n x n row-major, +inf = forbidden.  Returns 0 on success, -1 infeasible. */
+static int lsap_square(const double* cost, int n, int* col4row)
+{
+    double* u = (double*)calloc((size_t)n, sizeof(double));
+    double* v = (double*)calloc((size_t)n, sizeof(double));
+    double* sp = (double*)malloc(sizeof(double) * (size_t)n);
+    int* path = (int*)malloc(sizeof(int) * (size_t)n);
+    int* row4col = (int*)malloc(sizeof(int) * (size_t)n);
+    char* SR = (char*)malloc((size_t)n), *SC = (char*)malloc((size_t)n);
+    int* remaining = (int*)malloc(sizeof(int) * (size_t)n);
+    int rc = 0;
+    for (int i = 0; i < n; ++i) { col4row[i] = -1; row4col[i] = -1; }
+    for (int cur = 0; cur < n && rc == 0; ++cur) {
+        double minval = 0.0;
+        int i = cur, sink = -1, nrem = n;
+        for (int j = 0; j < n; ++j) { remaining[j] = n - j - 1; sp[j] = INFINITY; }
+        memset(SR, 0, (size_t)n); memset(SC, 0, (size_t)n);
+        while (sink == -1) {
+            int index = -1;
+            double lowest = INFINITY;
+            SR[i] = 1;
+            for (int it = 0; it < nrem; ++it) {
+                int j = remaining[it];
+                double r = minval + cost[(size_t)i * n + j] - u[i] - v[j];
+                if (r < sp[j]) { path[j] = i; sp[j] = r; }
+                if (sp[j] < lowest || (sp[j] == lowest && row4col[j] == -1)) { lowest = sp[j]; index = it; }
+            }
+            minval = lowest;
+            if (minval == INFINITY) { rc = -1; break; }
+            int j = remaining[index];
+            if (row4col[j] == -1) sink = j; else i = row4col[j];
+            SC[j] = 1;
+            remaining[index] = remaining[--nrem];
+        }
+        if (rc) break;
+        u[cur] += minval;
+        for (int r = 0; r < n; ++r) if (SR[r] && r != cur) u[r] += minval - sp[col4row[r]];
+        for (int j = 0; j < n; ++j) if (SC[j]) v[j] -= minval - sp[j];
+        int j = sink;
+        while (1) {
+            int r = path[j];
+            row4col[j] = r;
+            int t = col4row[r]; col4row[r] = j; j = t;
+            if (r == cur) break;
+        }
+    }
+    free(u); free(v); free(sp); free(path); free(row4col); free(SR); free(SC); free(remaining);
+    return rc;
+}
+
+/* A: (M,2), B: (N,2) float64 diagrams, already cleaned (utils:182-187): finite,
+ * non-empty.  persim: rows with non-finite death dropped; empty -> (0,0);
+ * DUL = sklearn pairwise_distances (expansion formula); diagonal costs by a 45-degree
+ * rotation; (M+N)^2 block matrix with +inf off-diagonals; sum of matched costs. */
+ORC_EXPORT double orc_wasserstein(const double* A_in, int M_in, const double* B_in, int N_in)
+{
+    const double cp = 0.7071067811865476;   /* np.cos(np.pi/4) */
+    const double sp_ = 0.7071067811865475;  /* np.sin(np.pi/4) */
+    double zero2[2] = { 0.0, 0.0 };
+    double* A = (double*)malloc(sizeof(double) * 2 * (size_t)(M_in + 1));
+    double* B = (double*)malloc(sizeof(double) * 2 * (size_t)(N_in + 1));
+    int M = 0, N = 0;
+    for (int i = 0; i < M_in; ++i) if (isfinite(A_in[2 * i + 1])) { A[2 * M] = A_in[2 * i]; A[2 * M + 1] = A_in[2 * i + 1]; ++M; }
+    for (int i = 0; i < N_in; ++i) if (isfinite(B_in[2 * i + 1])) { B[2 * N] = B_in[2 * i]; B[2 * N + 1] = B_in[2 * i + 1]; ++N; }
+    if (M == 0) { A[0] = zero2[0]; A[1] = zero2[1]; M = 1; }
+    if (N == 0) { B[0] = zero2[0]; B[1] = zero2[1]; N = 1; }
+    int n = M + N;
+    double* D = (double*)malloc(sizeof(double) * (size_t)n * n);
+    for (int i = 0; i < n * n; ++i) D[i] = 0.0;
+    for (int i = 0; i < M; ++i) {
+        double xx = A[2 * i] * A[2 * i] + A[2 * i + 1] * A[2 * i + 1];
+        for (int j = 0; j < N; ++j) {
+            double yy = B[2 * j] * B[2 * j] + B[2 * j + 1] * B[2 * j + 1];
+            double dot = fma(A[2 * i + 1], B[2 * j + 1], A[2 * i] * B[2 * j]);
+            double d2 = -2.0 * dot; d2 += xx; d2 += yy;
+            if (!(d2 > 0.0)) d2 = 0.0;
+            D[(size_t)i * n + j] = sqrt(d2);
+        }
+        for (int j = 0; j < M; ++j) D[(size_t)i * n + N + j] = INFINITY;
+        D[(size_t)i * n + N + i] = fma(A[2 * i + 1], cp, -(A[2 * i] * sp_));   /* (S.R)[:,1] */
+    }
+    for (int i = 0; i < N; ++i) {
+        for (int j = 0; j < N; ++j) D[(size_t)(M + i) * n + j] = INFINITY;
+        D[(size_t)(M + i) * n + i] = fma(B[2 * i + 1], cp, -(B[2 * i] * sp_));
+    }
+    int* col4row = (int*)malloc(sizeof(int) * (size_t)n);
+    double total = NAN;
+    if (lsap_square(D, n, col4row) == 0) {
+        double* m = (double*)malloc(sizeof(double) * (size_t)n);
+        for (int i = 0; i < n; ++i) m[i] = D[(size_t)i * n + col4row[i]];
+        total = np_pairwise_sum(m, n);
+        free(m);
+    }
+    free(A); free(B); free(D); free(col4row);
+    return total;
+}
+
+/* ------------------------------------------------------------------------- */
+/* batch helpers used by tests and by the cpu_baseline timing leg             */
+/* ------------------------------------------------------------------------- */
+ORC_EXPORT void orc_corr_dist_batch(const double* win, int n_win, int n_ch, int n_t,
+                                    double* corr_out, double* dist_out)
+{
+    for (int w = 0; w < n_win; ++w)
+        orc_corr_dist(win + (size_t)w * n_ch * n_t, n_ch, n_t,
+                      corr_out ? corr_out + (size_t)w * n_ch * n_ch : 0,
+                      dist_out ? dist_out + (size_t)w * n_ch * n_ch : 0);
+}
+
+ORC_EXPORT int orc_rips_dm_batch(const double* dist, int n_win, int n, double thresh, int symmetrise,
+                                 float* h0, int h0_cap, int* n_h0,
+                                 float* h1, int h1_cap, int* n_h1)
+{
+    int st = 0;
+    for (int w = 0; w < n_win; ++w)
+        st |= orc_rips_dm(dist + (size_t)w * n * n, n, thresh, symmetrise,
+                          h0 + (size_t)w * h0_cap * 2, h0_cap, n_h0 + w,
+                          h1 + (size_t)w * h1_cap * 2, h1_cap, n_h1 + w);
+    return st;
+}
