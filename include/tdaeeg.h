@@ -1,0 +1,186 @@
+/*
+ * tdaeeg.h -- C ABI of libtdaeeg.so: the MI355X (gfx950) persistent-homology
+ * feature engine for the per-window hot path of Ignaciagothe/tda-eeg-audio.
+ *
+ * The reference has no FFI: its boundary is the Python call level (SURVEY.md
+ * section 8b).  Each entry point below names the reference call it replaces
+ * (paths relative to the reference tree; notebooks cited by raw .ipynb JSON line).
+ *
+ * Conventions
+ *   * Plain C, no torch / HIP types in signatures.  `stream` is a hipStream_t
+ *     passed as void* (NULL = the default stream).
+ *   * `*_dev` entry points take DEVICE pointers, enqueue on `stream` and return
+ *     without synchronising (safe to capture in a hipGraph).  The un-suffixed
+ *     twins take HOST pointers, stage through the context's device workspace and
+ *     synchronise before returning.
+ *   * Every function returns a tda_status (0 = ok); nothing throws or aborts.
+ *     Per-window problems are reported in the `status` arrays (bit flags below),
+ *     never silently.
+ *   * The library keeps no pointer after a call returns and never writes inputs.
+ *   * Persistence diagrams are rows of (birth, death) float64 holding float32-exact
+ *     values (what ripser returns), +inf for essential classes.
+ *       H0: finite rows in ascending death order, then one (0,+inf) per component.
+ *       H1: rows in descending birth order (ripser's column order).
+ */
+#ifndef TDAEEG_H
+#define TDAEEG_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct tda_ctx tda_ctx;
+
+typedef enum {
+    TDA_OK = 0,
+    TDA_ERR_INVALID = 1,      /* bad argument (null pointer, size out of range) */
+    TDA_ERR_HIP = 2,          /* a HIP runtime call failed; see tda_last_error */
+    TDA_ERR_UNSUPPORTED = 3,  /* size outside what the kernels implement        */
+    TDA_ERR_NOMEM = 4
+} tda_status;
+
+/* per-window status bits written by the kernels */
+#define TDA_WIN_OK            0
+#define TDA_WIN_H1_TRUNCATED  1   /* more H1 rows than h1_cap; count holds the true number    */
+#define TDA_WIN_CLASS_OVERFLOW 2  /* more simultaneously alive H1 classes than the kernel's
+                                     class capacity (tda_set_class_words); diagrams invalid   */
+#define TDA_WIN_DEGENERATE    4   /* point cloud with < 3 points: diagrams are [[0,0]],[[0,0]]
+                                     exactly as scripts/utils.py:125-126                      */
+#define TDA_WIN_NOT_CONVERGED 8   /* assignment solver hit its iteration bound (-> NaN)        */
+#define TDA_WIN_TOO_LARGE     16  /* more than TDA_MAX_POINTS points (tau < 1?): no diagram    */
+
+#define TDA_N_FEATURES 11         /* scripts/utils.py:166-177 key order */
+#define TDA_MAX_POINTS 128        /* vertices per Rips complex (reference needs <= 124)        */
+#define TDA_MAX_DIM    4          /* Takens embedding dimension (reference uses 3)             */
+
+int  tda_version(void);
+
+/* Context: owns the HIP device binding, a stream-ordered workspace and the error
+ * string.  One per process and GPU (the reference's joblib workers, v2:569-572,
+ * become one process per GPU). */
+tda_status tda_ctx_create(int device_id, tda_ctx** out);
+void       tda_ctx_destroy(tda_ctx* ctx);
+/* Copies the last error message of this context (or of the failed create when
+ * ctx == NULL) into buf; returns its length. */
+size_t     tda_last_error(const tda_ctx* ctx, char* buf, size_t cap);
+/* Capacity for simultaneously alive H1 classes = 64 * words, words in {1,2,4}.
+ * Defaults: 2 for distance-matrix input, 1 for point clouds. */
+tda_status tda_set_class_words(tda_ctx* ctx, int words_dm, int words_cloud);
+
+/* ---- corr -> distance ------------------------------------------------------
+ * replaces compute_correlation_matrix + correlation_to_distance(method="euclidean")
+ * (notebooks/2_graph_construction.ipynb:86-122) and the per-window loop of
+ * process_file_graphs (nb2:198-207).
+ * win  : (n_win, n_ch, n_t) float64, C order   (preprocessed/<cond>/<rec>/<band>.npy)
+ * dist : (n_win, n_ch, n_ch) float64           (<band>_distances.npy)
+ * corr : same shape or NULL                    (<band>_correlations.npy)            */
+tda_status tda_corr_dist_batch_dev(tda_ctx* ctx, const double* win, int n_win, int n_ch, int n_t,
+                                   double* dist, double* corr, void* stream);
+tda_status tda_corr_dist_batch(tda_ctx* ctx, const double* win, int n_win, int n_ch, int n_t,
+                               double* dist, double* corr);
+
+/* ---- Vietoris-Rips H0/H1 from distance matrices -----------------------------
+ * replaces compute_eeg_persistence (scripts/utils.py:135-141) ==
+ * compute_persistence_diagram (scripts/tda_eeg_classification_v2.py:143-176):
+ * ripser(dm, maxdim=1, thresh, distance_matrix=True)["dgms"].
+ * dm        : (n_win, n, n) float64, n <= TDA_MAX_POINTS
+ * symmetrise: 1 = apply (D+D^T)/2, diag 0, max(.,0) first (utils.py:137-139);
+ *             0 = use entries (i,j), i<j, as ripser.py does on a raw matrix
+ * h0        : (n_win, h0_cap, 2) float64, h0_cap >= n;   h0_cnt: (n_win) int32
+ * h1        : (n_win, h1_cap, 2) float64;                h1_cnt: (n_win) int32
+ * status    : (n_win) int32 bit flags (TDA_WIN_*)                                    */
+tda_status tda_rips_dm_batch_dev(tda_ctx* ctx, const double* dm, int n_win, int n, double thresh,
+                                 int symmetrise, double* h0, int h0_cap, int* h0_cnt,
+                                 double* h1, int h1_cap, int* h1_cnt, int* status, void* stream);
+tda_status tda_rips_dm_batch(tda_ctx* ctx, const double* dm, int n_win, int n, double thresh,
+                             int symmetrise, double* h0, int h0_cap, int* h0_cnt,
+                             double* h1, int h1_cap, int* h1_cnt, int* status);
+
+/* ---- Takens embedding + Rips (audio branch) ---------------------------------
+ * replaces takens_embedding (scripts/utils.py:107-116) followed by
+ * compute_audio_persistence (utils.py:123-132): per-column min-max to [0,1],
+ * ripser(pc_norm, maxdim=1, thresh) whose point-cloud path is
+ * sklearn.metrics.pairwise_distances -> float32.
+ * win  : (n_win, n_t) float64 audio windows;  tau: (n_win) int32 delays
+ * n_points (out, nullable): points per window, P = ceil((n_t-(dim-1)tau)/subsample)
+ * Windows with P < 3 get [[0,0]],[[0,0]] and TDA_WIN_DEGENERATE (utils.py:125-126).  */
+tda_status tda_takens_rips_batch_dev(tda_ctx* ctx, const double* win, const int* tau, int n_win,
+                                     int n_t, int dim, int subsample, double thresh,
+                                     double* h0, int h0_cap, int* h0_cnt,
+                                     double* h1, int h1_cap, int* h1_cnt,
+                                     int* n_points, int* status, void* stream);
+tda_status tda_takens_rips_batch(tda_ctx* ctx, const double* win, const int* tau, int n_win,
+                                 int n_t, int dim, int subsample, double thresh,
+                                 double* h0, int h0_cap, int* h0_cnt,
+                                 double* h1, int h1_cap, int* h1_cnt,
+                                 int* n_points, int* status);
+
+/* ---- Rips from explicit point clouds ----------------------------------------
+ * replaces compute_audio_persistence(point_cloud) (utils.py:123-132) when the caller
+ * already holds the (P, dim) cloud.  pc: (n_win, p_cap, dim) float64; n_pts: (n_win). */
+tda_status tda_cloud_rips_batch_dev(tda_ctx* ctx, const double* pc, const int* n_pts, int n_win,
+                                    int p_cap, int dim, int normalise, double thresh,
+                                    double* h0, int h0_cap, int* h0_cnt,
+                                    double* h1, int h1_cap, int* h1_cnt, int* status, void* stream);
+tda_status tda_cloud_rips_batch(tda_ctx* ctx, const double* pc, const int* n_pts, int n_win,
+                                int p_cap, int dim, int normalise, double thresh,
+                                double* h0, int h0_cap, int* h0_cnt,
+                                double* h1, int h1_cap, int* h1_cnt, int* status);
+
+/* ---- delay from the first zero crossing of the autocorrelation ---------------
+ * replaces compute_tau (scripts/utils.py:92-104). max_lag < 0 = None (len/4).         */
+tda_status tda_tau_batch_dev(tda_ctx* ctx, const double* win, int n_win, int n_t, int max_lag,
+                             int* tau, void* stream);
+tda_status tda_tau_batch(tda_ctx* ctx, const double* win, int n_win, int n_t, int max_lag, int* tau);
+
+/* ---- 11 scalar features per diagram ------------------------------------------
+ * replaces extract_features (scripts/utils.py:144-177) ==
+ * extract_persistence_features (tda_eeg_classification_v2.py:179-250).
+ * dgm: (n_dgm, cap, 2) float64; cnt: (n_dgm); feat: (n_dgm, 11) float64.             */
+tda_status tda_features_batch_dev(tda_ctx* ctx, const double* dgm, const int* cnt, int n_dgm,
+                                  int cap, double* feat, void* stream);
+tda_status tda_features_batch(tda_ctx* ctx, const double* dgm, const int* cnt, int n_dgm,
+                              int cap, double* feat);
+
+/* ---- per-recording aggregation -------------------------------------------------
+ * replaces the mean/std over windows of process_file_features
+ * (tda_eeg_classification_v2.py:429-436).
+ * feat_h0, feat_h1 : (n_total, 11) float64 features of the used windows, grouped
+ * seg_off          : (n_seg+1) int32 offsets of each (recording, band) group
+ * out              : (n_seg, 44) float64 in the column order of features/feature_names.txt
+ *                    within one band: per feature {h0 mean, h0 std, h1 mean, h1 std}.  */
+tda_status tda_aggregate_batch_dev(tda_ctx* ctx, const double* feat_h0, const double* feat_h1,
+                                   const int* seg_off, int n_seg, double* out, void* stream);
+tda_status tda_aggregate_batch(tda_ctx* ctx, const double* feat_h0, const double* feat_h1,
+                               const int* seg_off, int n_seg, int n_total, double* out);
+
+/* ---- Wasserstein distance between diagrams ------------------------------------
+ * replaces safe_wasserstein (scripts/utils.py:180-191) -> persim.wasserstein
+ * (order 1, Euclidean ground metric, diagonal cost (d-b)/sqrt 2).
+ * dgm_a: (n_a, cap_a, 2), cnt_a: (n_a);  dgm_b likewise.
+ * idx_a, idx_b: (n_pairs) int32 diagram indices to pair (NULL = identity).
+ * Rows with a non-finite entry are ignored and an empty diagram becomes {(0,0)}
+ * (utils.py:182-187).  out: (n_pairs) float64, NaN where status != 0.                 */
+tda_status tda_wasserstein_batch_dev(tda_ctx* ctx, const double* dgm_a, const int* cnt_a, int cap_a,
+                                     const double* dgm_b, const int* cnt_b, int cap_b,
+                                     const int* idx_a, const int* idx_b, int n_pairs,
+                                     double* out, int* status, void* stream);
+tda_status tda_wasserstein_batch(tda_ctx* ctx, const double* dgm_a, const int* cnt_a, int n_a, int cap_a,
+                                 const double* dgm_b, const int* cnt_b, int n_b, int cap_b,
+                                 const int* idx_a, const int* idx_b, int n_pairs,
+                                 double* out, int* status);
+
+/* ---- timing helper ------------------------------------------------------------
+ * HIP-event timing on the stream the kernels are launched on (bench.py roofline). */
+tda_status tda_event_create(tda_ctx* ctx, void** ev);
+tda_status tda_event_record(tda_ctx* ctx, void* ev, void* stream);
+tda_status tda_event_elapsed_ms(tda_ctx* ctx, void* ev_start, void* ev_stop, float* ms); /* syncs on stop */
+tda_status tda_event_destroy(tda_ctx* ctx, void* ev);
+tda_status tda_stream_sync(tda_ctx* ctx, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TDAEEG_H */

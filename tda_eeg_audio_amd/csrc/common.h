@@ -1,0 +1,73 @@
+// common.h -- shared host/device helpers of libtdaeeg (gfx950 only, wave64).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include "../../include/tdaeeg.h"
+
+typedef unsigned long long u64;
+typedef uint32_t u32;
+typedef uint16_t u16;
+
+struct tda_ctx {
+    int device = 0;
+    int words_dm = 2;       // H1 class capacity (x64) for distance-matrix input
+    int words_cloud = 1;    // ... for point clouds
+    // host-API staging workspace (grown on demand, only by the host-pointer twins)
+    void* ws = nullptr;
+    size_t ws_bytes = 0;
+    std::string err;
+};
+
+#define TDA_HIP(ctx, call)                                                          \
+    do {                                                                            \
+        hipError_t e__ = (call);                                                    \
+        if (e__ != hipSuccess) {                                                    \
+            (ctx)->err = std::string(#call) + ": " + hipGetErrorString(e__);        \
+            return TDA_ERR_HIP;                                                     \
+        }                                                                           \
+    } while (0)
+
+#define TDA_FAIL(ctx, code, msg)                                                    \
+    do { (ctx)->err = (msg); return (code); } while (0)
+
+// ---- wave64 cross-lane helpers (lane index must be wave-uniform) ----
+__device__ __forceinline__ u32 rl32(u32 v, int lane) { return (u32)__builtin_amdgcn_readlane((int)v, lane); }
+__device__ __forceinline__ u64 rl64(u64 v, int lane)
+{
+    u32 lo = rl32((u32)v, lane), hi = rl32((u32)(v >> 32), lane);
+    return ((u64)hi << 32) | lo;
+}
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ u64 uni64(u64 v)
+{
+    u32 lo = (u32)__builtin_amdgcn_readfirstlane((int)(u32)v);
+    u32 hi = (u32)__builtin_amdgcn_readfirstlane((int)(u32)(v >> 32));
+    return ((u64)hi << 32) | lo;
+}
+__device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
+
+// order-preserving float32 <-> uint32 (handles negative values; NaN sorts last)
+__device__ __forceinline__ u32 f32_sortable(float f)
+{
+    u32 b = __float_as_uint(f);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__device__ __forceinline__ float sortable_f32(u32 s)
+{
+    u32 b = (s & 0x80000000u) ? (s & 0x7fffffffu) : ~s;
+    return __uint_as_float(b);
+}
+
+// launch-side entry points implemented in the .hip files
+tda_status launch_corr_dist(tda_ctx*, const double*, int, int, int, double*, double*, hipStream_t);
+tda_status launch_rips_dm(tda_ctx*, const double*, int, int, double, int, double*, int, int*, double*, int, int*,
+                          int*, hipStream_t);
+tda_status launch_rips_cloud(tda_ctx*, const double* win_or_pc, const int* tau_or_npts, int n_win, int n_t_or_pcap,
+                             int dim, int subsample, int mode, int normalise, double thresh, double*, int, int*,
+                             double*, int, int*, int* n_points, int*, hipStream_t);
+tda_status launch_tau(tda_ctx*, const double*, int, int, int, int*, hipStream_t);
+tda_status launch_features(tda_ctx*, const double*, const int*, int, int, double*, hipStream_t);
+tda_status launch_aggregate(tda_ctx*, const double*, const double*, const int*, int, double*, hipStream_t);
+tda_status launch_wasserstein(tda_ctx*, const double*, const int*, int, const double*, const int*, int, const int*,
+                              const int*, int, double*, int*, hipStream_t);

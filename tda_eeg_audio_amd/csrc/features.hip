@@ -1,0 +1,228 @@
+// features.hip -- small per-window kernels around the Rips core, gfx950 / wave64.
+//
+//   tau_kernel        replaces compute_tau                  (scripts/utils.py:92-104)
+//   features_kernel   replaces extract_features             (scripts/utils.py:144-177)
+//                     == extract_persistence_features       (tda_eeg_classification_v2.py:179-250)
+//   aggregate_kernel  replaces the mean/std over windows    (tda_eeg_classification_v2.py:429-436)
+//
+// All float64.  Sums follow numpy's pairwise-summation tree (8 interleaved partial sums for
+// n <= 128, halving above) so that mean/std agree with np.mean/np.std to the last bit on the
+// same input order; log() is OCML's, so the entropy is compared with a 1e-12 tolerance.
+#include "common.h"
+
+// numpy's pairwise sum over f(lo) .. f(lo+n-1), evaluated redundantly by every lane that
+// calls it (n is tiny: <= a few hundred)
+template <class F>
+__device__ double np_pairwise_fn(const F& f, int lo, int n)
+{
+    if (n < 8) {
+        double res = 0.0;
+        for (int i = 0; i < n; ++i) res += f(lo + i);
+        return res;
+    } else if (n <= 128) {
+        double r0 = f(lo), r1 = f(lo + 1), r2 = f(lo + 2), r3 = f(lo + 3);
+        double r4 = f(lo + 4), r5 = f(lo + 5), r6 = f(lo + 6), r7 = f(lo + 7);
+        int i;
+        for (i = 8; i < n - (n % 8); i += 8) {
+            r0 += f(lo + i + 0); r1 += f(lo + i + 1); r2 += f(lo + i + 2); r3 += f(lo + i + 3);
+            r4 += f(lo + i + 4); r5 += f(lo + i + 5); r6 += f(lo + i + 6); r7 += f(lo + i + 7);
+        }
+        double res = ((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7));
+        for (; i < n; ++i) res += f(lo + i);
+        return res;
+    } else {
+        int n2 = n / 2;
+        n2 -= n2 % 8;
+        return np_pairwise_fn(f, lo, n2) + np_pairwise_fn(f, lo + n2, n - n2);
+    }
+}
+
+__device__ double np_pairwise_sum(const double* a, int n, int stride)
+{
+    auto f = [=](int i) { return a[(size_t)i * stride]; };
+    return np_pairwise_fn(f, 0, n);
+}
+
+// ---------------------------------------------------------------------------------
+// compute_tau: first lag k in [1, min(max_lag, len)) whose autocorrelation is <= 0.
+// One wave per window; lane l owns lags l+1 and l+65 (max_lag <= 128), each a
+// sequential fma chain over t (the order oracle/tda_oracle.c::orc_compute_tau fixes).
+// ---------------------------------------------------------------------------------
+__global__ void __launch_bounds__(64)
+tau_kernel(const double* __restrict__ win, int n_win, int n_t, int max_lag, int* __restrict__ tau)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    double* sc = reinterpret_cast<double*>(smem);
+    const int w = blockIdx.x;
+    if (w >= n_win) return;
+    const int lane = lane_id();
+    const double* s = win + (size_t)w * n_t;
+    for (int t = lane; t < n_t; t += 64) sc[t] = s[t];
+    __syncthreads();
+    double sum = 0.0;
+    for (int t = 0; t < n_t; ++t) sum += sc[t];     // every lane: same sequential sum
+    const double m = sum / (double)n_t;
+    __syncthreads();
+    for (int t = lane; t < n_t; t += 64) sc[t] = sc[t] - m;
+    __syncthreads();
+    if (max_lag < 0) max_lag = n_t / 4;             // utils.py:94-95
+    if (max_lag > n_t - 1) max_lag = n_t - 1;       // utils.py:96
+    const int lim = max_lag < n_t ? max_lag : n_t;  // utils.py:101
+    int found = 0;
+    for (int k0 = 1; k0 < lim && !found; k0 += 64) {
+        const int k = k0 + lane;
+        double acc = 1.0;
+        if (k < lim) {
+            acc = 0.0;
+            for (int t = 0; t + k < n_t; ++t) acc = fma(sc[t + k], sc[t], acc);
+        }
+        const u64 bal = __ballot(k < lim && acc <= 0.0);
+        if (bal) found = k0 + __builtin_ctzll(bal);
+    }
+    if (!found) { found = max_lag / 10; if (found < 1) found = 1; }
+    if (lane == 0) tau[w] = found;
+}
+
+// ---------------------------------------------------------------------------------
+// extract_features: 11 scalars per diagram, key order of utils.py:166-177
+// ---------------------------------------------------------------------------------
+__global__ void __launch_bounds__(64)
+features_kernel(const double* __restrict__ dgm, const int* __restrict__ cnt, int n_dgm, int cap,
+                double* __restrict__ feat)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    double* b = reinterpret_cast<double*>(smem);    // births | deaths | pers | tmp, cap each
+    double* d = b + cap;
+    double* p = d + cap;
+    double* tmp = p + cap;
+    const int g = blockIdx.x;
+    if (g >= n_dgm) return;
+    const int lane = lane_id();
+    int k = cnt[g];
+    k = k < cap ? k : cap;
+    const double* rows = dgm + (size_t)g * cap * 2;
+    // compact finite rows, preserving order (utils.py:146-147)
+    int m = 0, ness = 0;
+    for (int i0 = 0; i0 < k; i0 += 64) {
+        const int i = i0 + lane;
+        double bi = 0.0, di = 0.0;
+        bool fin = false, valid = i < k;
+        if (valid) { bi = rows[2 * i]; di = rows[2 * i + 1]; fin = isfinite(bi) && isfinite(di); }
+        const u64 bal = __ballot(fin);
+        const int pos = m + __popcll(bal & ((1ull << lane) - 1ull));
+        if (fin) { b[pos] = bi; d[pos] = di; p[pos] = di - bi; }
+        m += __popcll(bal);
+        ness += __popcll(__ballot(valid && !fin));
+    }
+    __syncthreads();
+    double out[TDA_N_FEATURES];
+#pragma unroll
+    for (int i = 0; i < TDA_N_FEATURES; ++i) out[i] = 0.0;
+    out[1] = (double)ness;
+    if (m > 0) {
+        out[0] = (double)m;
+        const double* arr[3] = {b, d, p};
+        for (int q = 0; q < 3; ++q) {
+            const double mean = np_pairwise_sum(arr[q], m, 1) / (double)m;
+            out[2 + 2 * q] = mean;
+            if (m > 1) {
+                __syncthreads();
+                for (int i = lane; i < m; i += 64) { const double z = arr[q][i] - mean; tmp[i] = z * z; }
+                __syncthreads();
+                out[3 + 2 * q] = sqrt(np_pairwise_sum(tmp, m, 1) / (double)m);
+            }
+        }
+        double mx = -INFINITY;
+        for (int i = lane; i < m; i += 64) mx = p[i] > mx ? p[i] : mx;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) { const double o = __shfl_xor(mx, off, 64); mx = o > mx ? o : mx; }
+        out[8] = mx;
+        const double tot = np_pairwise_sum(p, m, 1);
+        out[9] = tot;
+        if (m > 1 && tot > 0.0) {
+            __syncthreads();
+            // pn = pers/sum; keep pn > 0 in order (utils.py:161-163)
+            int c = 0;
+            for (int i0 = 0; i0 < m; i0 += 64) {
+                const int i = i0 + lane;
+                double pn = 0.0;
+                if (i < m) pn = p[i] / tot;
+                const bool pos = i < m && pn > 0.0;
+                const u64 bal = __ballot(pos);
+                const int at = c + __popcll(bal & ((1ull << lane) - 1ull));
+                if (pos) tmp[at] = pn * log(pn + 1e-10);
+                c += __popcll(bal);
+            }
+            __syncthreads();
+            out[10] = -np_pairwise_sum(tmp, c, 1) / log((double)m + 1e-10);
+        }
+    }
+    if (lane < TDA_N_FEATURES) {
+        double v = 0.0;
+#pragma unroll
+        for (int i = 0; i < TDA_N_FEATURES; ++i) v = (lane == i) ? out[i] : v;
+        feat[(size_t)g * TDA_N_FEATURES + lane] = v;
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// per (recording, band) aggregation: np.mean / np.std over the used windows
+// out[seg][f*4 + {0,1,2,3}] = h0 mean, h0 std, h1 mean, h1 std   (v2:429-436)
+// ---------------------------------------------------------------------------------
+__global__ void __launch_bounds__(64)
+aggregate_kernel(const double* __restrict__ f0, const double* __restrict__ f1, const int* __restrict__ seg_off,
+                 int n_seg, double* __restrict__ out)
+{
+    const int seg = blockIdx.x;
+    if (seg >= n_seg) return;
+    const int lane = lane_id();
+    if (lane >= 2 * TDA_N_FEATURES) return;
+    const int h = lane / TDA_N_FEATURES, f = lane % TDA_N_FEATURES;
+    const int s0 = seg_off[seg], s1 = seg_off[seg + 1];
+    const int n = s1 - s0;
+    const double* src = (h == 0 ? f0 : f1) + (size_t)s0 * TDA_N_FEATURES + f;
+    double mean = 0.0, sd = 0.0;
+    if (n > 0) {
+        mean = np_pairwise_sum(src, n, TDA_N_FEATURES) / (double)n;
+        // np.std = sqrt(mean(|x-mean|^2)), same pairwise tree evaluated on the fly
+        auto sq = [=](int i) { const double z = src[(size_t)i * TDA_N_FEATURES] - mean; return z * z; };
+        const double res = np_pairwise_fn(sq, 0, n);
+        sd = sqrt(res / (double)n);
+    }
+    double* o = out + (size_t)seg * (4 * TDA_N_FEATURES) + f * 4 + h * 2;
+    o[0] = mean;
+    o[1] = sd;
+}
+
+// ---------------------------------------------------------------------------------
+tda_status launch_tau(tda_ctx* ctx, const double* win, int n_win, int n_t, int max_lag, int* tau, hipStream_t st)
+{
+    if (n_win == 0) return TDA_OK;
+    if (n_t < 2 || n_t > 8192) TDA_FAIL(ctx, TDA_ERR_UNSUPPORTED, "n_t must be in [2,8192]");
+    hipLaunchKernelGGL(tau_kernel, dim3(n_win), dim3(64), (size_t)n_t * 8, st, win, n_win, n_t, max_lag, tau);
+    TDA_HIP(ctx, hipGetLastError());
+    return TDA_OK;
+}
+
+tda_status launch_features(tda_ctx* ctx, const double* dgm, const int* cnt, int n_dgm, int cap, double* feat,
+                           hipStream_t st)
+{
+    if (n_dgm == 0) return TDA_OK;
+    if (cap < 1 || cap > 2048) TDA_FAIL(ctx, TDA_ERR_UNSUPPORTED, "diagram capacity must be in [1,2048]");
+    const size_t lds = (size_t)cap * 4 * 8;
+    if (lds > 48 * 1024)
+        TDA_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(features_kernel),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(features_kernel, dim3(n_dgm), dim3(64), lds, st, dgm, cnt, n_dgm, cap, feat);
+    TDA_HIP(ctx, hipGetLastError());
+    return TDA_OK;
+}
+
+tda_status launch_aggregate(tda_ctx* ctx, const double* f0, const double* f1, const int* seg_off, int n_seg,
+                            double* out, hipStream_t st)
+{
+    if (n_seg == 0) return TDA_OK;
+    hipLaunchKernelGGL(aggregate_kernel, dim3(n_seg), dim3(64), 0, st, f0, f1, seg_off, n_seg, out);
+    TDA_HIP(ctx, hipGetLastError());
+    return TDA_OK;
+}

@@ -1,0 +1,282 @@
+// wasserstein.hip -- batched order-1 Wasserstein distance between persistence diagrams.
+//
+// Replaces safe_wasserstein (scripts/utils.py:180-191) -> persim.wasserstein(dgm1, dgm2):
+// Euclidean ground metric (sklearn's |x|^2 - 2x.y + |y|^2 expansion, float64), every point
+// may instead go to the diagonal at cost (d-b)cos(pi/4)-ish (persim's 45-degree rotation),
+// result = plain sum of matched costs.
+//
+// persim solves one (M+N)x(M+N) assignment with +inf blocks.  The same optimum is the
+// min over PARTIAL matchings mu of  sum_mu C_ij + sum_{i not in mu} s_i + sum_{j not in mu} t_j
+//   =  sum s + sum t + min_mu sum_mu (C_ij - s_i - t_j),
+// i.e. a rectangular assignment (rows = the smaller diagram) with costs
+// g_ij = min(0, C_ij - s_i - t_j) <= 0 and no forbidden entries.  It is solved EXACTLY in
+// float64 by shortest augmenting paths with dual variables (Jonker-Volgenant class), one
+// pair per wavefront: columns live on lanes (CW per lane), one Dijkstra step = CW LDS reads
+// per lane + one wave min-reduction.  At most R(R+1)/2 steps for R rows.
+// The returned value re-sums the ORIGINAL costs (C_ij, s_i, t_j) of the optimal matching.
+#include "common.h"
+
+#define WS_CP 0.7071067811865476   // np.cos(np.pi/4)
+#define WS_SP 0.7071067811865475   // np.sin(np.pi/4)
+
+__device__ __forceinline__ double wave_sum_f64(double v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+__device__ __forceinline__ double wave_min_f64_ws(double v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const double o = __shfl_xor(v, off, 64);
+        v = o < v ? o : v;
+    }
+    return v;
+}
+
+// C(a_i, b_j) with a from the FIRST diagram and b from the SECOND, independent of which one
+// plays the row role (mirrors oracle/tda_oracle.c::orc_wasserstein)
+__device__ __forceinline__ double ws_cost(double ab, double ad, double bb, double bd)
+{
+    const double xx = ab * ab + ad * ad;
+    const double yy = bb * bb + bd * bd;
+    const double dot = fma(ad, bd, ab * bb);
+    double d2 = -2.0 * dot;
+    d2 += xx;
+    d2 += yy;
+    if (!(d2 > 0.0)) d2 = 0.0;
+    return sqrt(d2);
+}
+
+template <int CW>
+__global__ void __launch_bounds__(64)
+wasserstein_kernel(const double* __restrict__ dgm_a, const int* __restrict__ cnt_a, int cap_a,
+                   const double* __restrict__ dgm_b, const int* __restrict__ cnt_b, int cap_b,
+                   const int* __restrict__ idx_a, const int* __restrict__ idx_b, int n_pairs,
+                   int max_rows, int max_cols, int use_matrix,
+                   double* __restrict__ out, int* __restrict__ status)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int pr = blockIdx.x;
+    if (pr >= n_pairs) return;
+    const int lane = lane_id();
+    // LDS: row points (b,d,s) | col points (b,d,t) | u[rows] | cost matrix (optional)
+    double* rb = reinterpret_cast<double*>(smem);
+    double* rd = rb + max_rows;
+    double* rs = rd + max_rows;
+    double* ru = rs + max_rows;
+    double* cb = ru + max_rows;
+    double* cd = cb + max_cols;
+    double* ct = cd + max_cols;
+    double* G = ct + max_cols;          // max_rows x max_cols when use_matrix
+
+    const int ia = idx_a ? idx_a[pr] : pr;
+    const int ib = idx_b ? idx_b[pr] : pr;
+    const double* A = dgm_a + (size_t)ia * cap_a * 2;
+    const double* B = dgm_b + (size_t)ib * cap_b * 2;
+    int ka = cnt_a[ia]; ka = ka < cap_a ? ka : cap_a; ka = ka < 0 ? 0 : ka;
+    int kb = cnt_b[ib]; kb = kb < cap_b ? kb : cap_b; kb = kb < 0 ? 0 : kb;
+    // count finite rows (utils.py:185-186)
+    int M = 0, N = 0;
+    for (int i0 = 0; i0 < ka; i0 += 64) {
+        const int i = i0 + lane;
+        M += __popcll(__ballot(i < ka && isfinite(A[2 * i]) && isfinite(A[2 * i + 1])));
+    }
+    for (int i0 = 0; i0 < kb; i0 += 64) {
+        const int i = i0 + lane;
+        N += __popcll(__ballot(i < kb && isfinite(B[2 * i]) && isfinite(B[2 * i + 1])));
+    }
+    const int Me = M > 0 ? M : 1, Ne = N > 0 ? N : 1;    // empty -> {(0,0)}  (utils.py:184,187)
+    // rows = smaller diagram
+    const bool a_is_row = Me <= Ne;
+    const int R = a_is_row ? Me : Ne, Cn = a_is_row ? Ne : Me;
+    if (R > max_rows || Cn > max_cols || Cn > 64 * CW) {
+        if (lane == 0) { out[pr] = __longlong_as_double(0x7ff8000000000000ll); status[pr] = TDA_WIN_NOT_CONVERGED; }
+        return;
+    }
+    // load finite points, preserving order
+    {
+        double* pb = a_is_row ? rb : cb; double* pd = a_is_row ? rd : cd; double* pc = a_is_row ? rs : ct;
+        int m = 0;
+        for (int i0 = 0; i0 < ka; i0 += 64) {
+            const int i = i0 + lane;
+            double b = 0, d = 0; bool fin = false;
+            if (i < ka) { b = A[2 * i]; d = A[2 * i + 1]; fin = isfinite(b) && isfinite(d); }
+            const u64 bal = __ballot(fin);
+            const int pos = m + __popcll(bal & ((1ull << lane) - 1ull));
+            if (fin) { pb[pos] = b; pd[pos] = d; pc[pos] = fma(d, WS_CP, -(b * WS_SP)); }
+            m += __popcll(bal);
+        }
+        if (M == 0 && lane == 0) { pb[0] = 0.0; pd[0] = 0.0; pc[0] = 0.0; }
+    }
+    {
+        double* pb = a_is_row ? cb : rb; double* pd = a_is_row ? cd : rd; double* pc = a_is_row ? ct : rs;
+        int m = 0;
+        for (int i0 = 0; i0 < kb; i0 += 64) {
+            const int i = i0 + lane;
+            double b = 0, d = 0; bool fin = false;
+            if (i < kb) { b = B[2 * i]; d = B[2 * i + 1]; fin = isfinite(b) && isfinite(d); }
+            const u64 bal = __ballot(fin);
+            const int pos = m + __popcll(bal & ((1ull << lane) - 1ull));
+            if (fin) { pb[pos] = b; pd[pos] = d; pc[pos] = fma(d, WS_CP, -(b * WS_SP)); }
+            m += __popcll(bal);
+        }
+        if (N == 0 && lane == 0) { pb[0] = 0.0; pd[0] = 0.0; pc[0] = 0.0; }
+    }
+    __syncthreads();
+
+    auto cfull = [&](int i, int j) -> double {   // original point-to-point cost of row i, col j
+        return a_is_row ? ws_cost(rb[i], rd[i], cb[j], cd[j]) : ws_cost(cb[j], cd[j], rb[i], rd[i]);
+    };
+    auto gain = [&](int i, int j) -> double {
+        const double g = cfull(i, j) - rs[i] - ct[j];
+        return g < 0.0 ? g : 0.0;
+    };
+    if (use_matrix) {
+        for (int e = lane; e < R * Cn; e += 64) { const int i = e / Cn, j = e - i * Cn; G[e] = gain(i, j); }
+    }
+    for (int i = lane; i < R; i += 64) ru[i] = 0.0;
+    __syncthreads();
+
+    // per-lane column state: column j = lane + 64*c
+    double v[CW], minv[CW];
+    int prow[CW], way[CW];
+    bool used[CW];
+#pragma unroll
+    for (int c = 0; c < CW; ++c) { v[c] = 0.0; prow[c] = -1; way[c] = -1; }
+
+    const double INF = __longlong_as_double(0x7ff0000000000000ll);
+    bool failed = false;
+    for (int i = 0; i < R && !failed; ++i) {
+#pragma unroll
+        for (int c = 0; c < CW; ++c) { minv[c] = INF; used[c] = false; }
+        int i0 = i, j0 = -1;            // j0 = -1 is the virtual start column holding row i
+        int steps = 0;
+        while (true) {
+            const double ui0 = ru[i0];
+            double best = INF;
+#pragma unroll
+            for (int c = 0; c < CW; ++c) {
+                const int j = lane + 64 * c;
+                if (j < Cn && !used[c]) {
+                    const double g = use_matrix ? G[i0 * Cn + j] : gain(i0, j);
+                    const double cur = g - ui0 - v[c];
+                    if (cur < minv[c]) { minv[c] = cur; way[c] = j0; }
+                    best = minv[c] < best ? minv[c] : best;
+                }
+            }
+            const double delta = wave_min_f64_ws(best);
+            // first column attaining delta
+            int j1 = -1;
+#pragma unroll
+            for (int c = CW - 1; c >= 0; --c) {
+                const int j = lane + 64 * c;
+                const u64 bal = __ballot(j < Cn && !used[c] && minv[c] == delta);
+                if (bal) j1 = 64 * c + __builtin_ctzll(bal);
+            }
+            if (j1 < 0 || !(delta < INF) || ++steps > Cn + 2) { failed = true; break; }
+            // dual update
+            __syncthreads();
+#pragma unroll
+            for (int c = 0; c < CW; ++c) {
+                if (used[c]) { ru[prow[c]] += delta; v[c] -= delta; }
+                else minv[c] -= delta;
+            }
+            if (lane == 0) ru[i] += delta;      // the virtual column's row
+            __syncthreads();
+            // mark j1 used, continue from its row
+            const int c1 = j1 >> 6, l1 = j1 & 63;
+            int p1 = -1;
+#pragma unroll
+            for (int c = 0; c < CW; ++c)
+                if (c == c1) {
+                    p1 = (int)rl32((u32)prow[c], l1);
+                    if (lane == l1) used[c] = true;
+                }
+            j0 = j1;
+            if (p1 < 0) break;          // free column reached: augment
+            i0 = p1;
+        }
+        if (failed) break;
+        // augment along way[] back to the virtual column
+        int guard = 0;
+        while (j0 >= 0 && guard++ < Cn + 2) {
+            const int c0 = j0 >> 6, l0 = j0 & 63;
+            int jprev = -1;
+#pragma unroll
+            for (int c = 0; c < CW; ++c)
+                if (c == c0) jprev = (int)rl32((u32)way[c], l0);
+            int newrow = i;
+            if (jprev >= 0) {
+                const int cp = jprev >> 6, lp = jprev & 63;
+#pragma unroll
+                for (int c = 0; c < CW; ++c)
+                    if (c == cp) newrow = (int)rl32((u32)prow[c], lp);
+            }
+#pragma unroll
+            for (int c = 0; c < CW; ++c)
+                if (c == c0 && lane == l0) prow[c] = newrow;
+            j0 = jprev;
+        }
+    }
+    if (failed) {
+        if (lane == 0) { out[pr] = __longlong_as_double(0x7ff8000000000000ll); status[pr] = TDA_WIN_NOT_CONVERGED; }
+        return;
+    }
+    // total = sum over real matches of C_ij + unmatched rows' s + unmatched cols' t
+    double part = 0.0;
+    __syncthreads();
+    // reuse ru[] as "row is really matched" flag
+    for (int i = lane; i < R; i += 64) ru[i] = 0.0;
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < CW; ++c) {
+        const int j = lane + 64 * c;
+        if (j < Cn) {
+            bool real = false;
+            if (prow[c] >= 0) {
+                const double cf = cfull(prow[c], j);
+                if (cf - rs[prow[c]] - ct[j] < 0.0) { real = true; part += cf; ru[prow[c]] = 1.0; }
+            }
+            if (!real) part += ct[j];
+        }
+    }
+    __syncthreads();
+    for (int i = lane; i < R; i += 64)
+        if (ru[i] == 0.0) part += rs[i];
+    const double total = wave_sum_f64(part);
+    if (lane == 0) { out[pr] = total; status[pr] = 0; }
+}
+
+// ---------------------------------------------------------------------------------
+tda_status launch_wasserstein(tda_ctx* ctx, const double* dgm_a, const int* cnt_a, int cap_a, const double* dgm_b,
+                              const int* cnt_b, int cap_b, const int* idx_a, const int* idx_b, int n_pairs,
+                              double* out, int* status, hipStream_t st)
+{
+    if (n_pairs == 0) return TDA_OK;
+    if (cap_a < 1 || cap_b < 1) TDA_FAIL(ctx, TDA_ERR_INVALID, "diagram capacity must be >= 1");
+    const int lo = cap_a < cap_b ? cap_a : cap_b, hi = cap_a < cap_b ? cap_b : cap_a;
+    const int max_rows = lo, max_cols = hi;
+    if (max_cols > 512) TDA_FAIL(ctx, TDA_ERR_UNSUPPORTED, "diagrams with more than 512 rows are not supported");
+    const size_t vec_bytes = (size_t)(4 * max_rows + 3 * max_cols) * 8;
+    const size_t mat_bytes = (size_t)max_rows * max_cols * 8;
+    int use_matrix = (vec_bytes + mat_bytes) <= 72 * 1024;
+    const size_t lds = vec_bytes + (use_matrix ? mat_bytes : 0);
+#define WS_LAUNCH(CWV)                                                                                         \
+    do {                                                                                                       \
+        auto kern = wasserstein_kernel<CWV>;                                                                   \
+        if (lds > 48 * 1024)                                                                                   \
+            TDA_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                              \
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));           \
+        hipLaunchKernelGGL(kern, dim3(n_pairs), dim3(64), lds, st, dgm_a, cnt_a, cap_a, dgm_b, cnt_b, cap_b,   \
+                           idx_a, idx_b, n_pairs, max_rows, max_cols, use_matrix, out, status);                \
+    } while (0)
+    if (max_cols <= 128) WS_LAUNCH(2);
+    else if (max_cols <= 256) WS_LAUNCH(4);
+    else WS_LAUNCH(8);
+#undef WS_LAUNCH
+    TDA_HIP(ctx, hipGetLastError());
+    return TDA_OK;
+}

@@ -1,0 +1,257 @@
+"""
+engine.py -- batched numpy / torch-tensor front end of libtdaeeg.so.
+
+Every function here is a thin marshalling layer over one C-ABI entry point of
+include/tdaeeg.h; all arithmetic happens in the HIP kernels.  There is no CPU path.
+
+  host arrays  : corr_dist_batch, rips_dm_batch, takens_rips_batch, cloud_rips_batch,
+                 tau_batch, features_batch, aggregate_batch, wasserstein_batch
+  device tensors (torch, already resident in HBM, launched on torch's current stream):
+                 the ``*_dev`` twins -- used by bench.py and the multi-GPU driver.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import f64, i32, ptr, get_ctx
+
+MAX_EDGE_LENGTH = 2.0      # scripts/utils.py:25
+DEFAULT_H1_CAP = 256
+
+
+def _diagrams(rows, cnt, cap):
+    """(n, cap, 2) rows + counts -> list of (k,2) float64 arrays."""
+    return [rows[i, :min(int(cnt[i]), cap)].copy() for i in range(rows.shape[0])]
+
+
+# ------------------------------------------------------------------ host-array API
+def corr_dist_batch(windows, want_corr=True, ctx=None):
+    ctx = ctx or get_ctx()
+    w = f64(windows)
+    n_win, n_ch, n_t = w.shape
+    dist = np.empty((n_win, n_ch, n_ch))
+    corr = np.empty((n_win, n_ch, n_ch)) if want_corr else None
+    ctx.check(ctx.lib.tda_corr_dist_batch(ctx.h, ptr(w), n_win, n_ch, n_t, ptr(dist), ptr(corr)))
+    return (corr, dist) if want_corr else dist
+
+
+def rips_dm_batch(dms, thresh=MAX_EDGE_LENGTH, symmetrise=True, h1_cap=DEFAULT_H1_CAP, ctx=None, raw=False):
+    ctx = ctx or get_ctx()
+    d = f64(dms)
+    n_win, n, n2 = d.shape
+    assert n == n2, "distance matrices must be square"   # the only thing ripser itself rejects
+    h0 = np.empty((n_win, n, 2)); h1 = np.empty((n_win, h1_cap, 2))
+    c0 = np.empty(n_win, np.int32); c1 = np.empty(n_win, np.int32); st = np.empty(n_win, np.int32)
+    ctx.check(ctx.lib.tda_rips_dm_batch(ctx.h, ptr(d), n_win, n, float(thresh), int(bool(symmetrise)),
+                                        ptr(h0), n, ptr(c0), ptr(h1), h1_cap, ptr(c1), ptr(st)))
+    if raw:
+        return h0, c0, h1, c1, st
+    return _diagrams(h0, c0, n), _diagrams(h1, c1, h1_cap), st
+
+
+def takens_rips_batch(windows, taus, dim=3, subsample=2, thresh=MAX_EDGE_LENGTH, h1_cap=DEFAULT_H1_CAP,
+                      ctx=None, raw=False):
+    ctx = ctx or get_ctx()
+    w = f64(windows)
+    n_win, n_t = w.shape
+    tau = i32(np.broadcast_to(np.asarray(taus), (n_win,)))
+    h0_cap = _lib.MAX_POINTS
+    h0 = np.empty((n_win, h0_cap, 2)); h1 = np.empty((n_win, h1_cap, 2))
+    c0 = np.empty(n_win, np.int32); c1 = np.empty(n_win, np.int32)
+    npts = np.empty(n_win, np.int32); st = np.empty(n_win, np.int32)
+    ctx.check(ctx.lib.tda_takens_rips_batch(ctx.h, ptr(w), ptr(tau), n_win, n_t, dim, subsample, float(thresh),
+                                            ptr(h0), h0_cap, ptr(c0), ptr(h1), h1_cap, ptr(c1), ptr(npts), ptr(st)))
+    if raw:
+        return h0, c0, h1, c1, npts, st
+    return _diagrams(h0, c0, h0_cap), _diagrams(h1, c1, h1_cap), npts, st
+
+
+def cloud_rips_batch(clouds, n_pts=None, normalise=True, thresh=MAX_EDGE_LENGTH, h1_cap=DEFAULT_H1_CAP,
+                     ctx=None, raw=False):
+    ctx = ctx or get_ctx()
+    pc = f64(clouds)
+    n_win, p_cap, dim = pc.shape
+    n_pts = i32(np.full(n_win, p_cap) if n_pts is None else n_pts)
+    h0_cap = max(p_cap, 3)
+    h0 = np.empty((n_win, h0_cap, 2)); h1 = np.empty((n_win, h1_cap, 2))
+    c0 = np.empty(n_win, np.int32); c1 = np.empty(n_win, np.int32); st = np.empty(n_win, np.int32)
+    ctx.check(ctx.lib.tda_cloud_rips_batch(ctx.h, ptr(pc), ptr(n_pts), n_win, p_cap, dim, int(bool(normalise)),
+                                           float(thresh), ptr(h0), h0_cap, ptr(c0), ptr(h1), h1_cap, ptr(c1),
+                                           ptr(st)))
+    if raw:
+        return h0, c0, h1, c1, st
+    return _diagrams(h0, c0, h0_cap), _diagrams(h1, c1, h1_cap), st
+
+
+def tau_batch(windows, max_lag=None, ctx=None):
+    ctx = ctx or get_ctx()
+    w = f64(windows)
+    n_win, n_t = w.shape
+    tau = np.empty(n_win, np.int32)
+    ctx.check(ctx.lib.tda_tau_batch(ctx.h, ptr(w), n_win, n_t, -1 if max_lag is None else int(max_lag), ptr(tau)))
+    return tau
+
+
+def pack_diagrams(dgms, cap=None):
+    """list of (k,2) arrays -> (n, cap, 2) float64 + counts."""
+    arrs = [np.asarray(d, dtype=np.float64).reshape(-1, 2) if np.asarray(d).ndim == 2 and np.asarray(d).size
+            else np.zeros((0, 2)) for d in dgms]
+    cap = cap or max(1, max((a.shape[0] for a in arrs), default=1))
+    rows = np.zeros((len(arrs), cap, 2))
+    cnt = np.zeros(len(arrs), np.int32)
+    for i, a in enumerate(arrs):
+        assert a.shape[0] <= cap
+        rows[i, :a.shape[0]] = a
+        cnt[i] = a.shape[0]
+    return rows, cnt
+
+
+def features_batch(rows, cnt, ctx=None):
+    ctx = ctx or get_ctx()
+    rows = f64(rows); cnt = i32(cnt)
+    n, cap, _ = rows.shape
+    feat = np.empty((n, _lib.N_FEATURES))
+    ctx.check(ctx.lib.tda_features_batch(ctx.h, ptr(rows), ptr(cnt), n, cap, ptr(feat)))
+    return feat
+
+
+def aggregate_batch(feat_h0, feat_h1, seg_off, ctx=None):
+    ctx = ctx or get_ctx()
+    f0 = f64(feat_h0); f1 = f64(feat_h1); off = i32(seg_off)
+    n_seg = len(off) - 1
+    out = np.empty((n_seg, 4 * _lib.N_FEATURES))
+    ctx.check(ctx.lib.tda_aggregate_batch(ctx.h, ptr(f0), ptr(f1), ptr(off), n_seg, f0.shape[0], ptr(out)))
+    return out
+
+
+def wasserstein_batch(rows_a, cnt_a, rows_b, cnt_b, idx_a=None, idx_b=None, ctx=None, want_status=False):
+    ctx = ctx or get_ctx()
+    ra = f64(rows_a); rb = f64(rows_b); ca = i32(cnt_a); cb = i32(cnt_b)
+    n_a, cap_a, _ = ra.shape
+    n_b, cap_b, _ = rb.shape
+    if idx_a is None and idx_b is None:
+        assert n_a == n_b
+        n_pairs = n_a
+    else:
+        n_pairs = len(idx_a if idx_a is not None else idx_b)
+    ia = None if idx_a is None else i32(idx_a)
+    ib = None if idx_b is None else i32(idx_b)
+    out = np.empty(n_pairs); st = np.empty(n_pairs, np.int32)
+    ctx.check(ctx.lib.tda_wasserstein_batch(ctx.h, ptr(ra), ptr(ca), n_a, cap_a, ptr(rb), ptr(cb), n_b, cap_b,
+                                            ptr(ia), ptr(ib), n_pairs, ptr(out), ptr(st)))
+    return (out, st) if want_status else out
+
+
+# ------------------------------------------------------------------ device-tensor API (torch)
+def _tp(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _stream():
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class DeviceDiagrams:
+    """H0/H1 rows of a batch of windows, resident in HBM."""
+
+    def __init__(self, n_win, h0_cap, h1_cap, device):
+        import torch
+        kw = dict(device=device)
+        self.h0 = torch.empty((n_win, h0_cap, 2), dtype=torch.float64, **kw)
+        self.h1 = torch.empty((n_win, h1_cap, 2), dtype=torch.float64, **kw)
+        self.c0 = torch.empty(n_win, dtype=torch.int32, **kw)
+        self.c1 = torch.empty(n_win, dtype=torch.int32, **kw)
+        self.status = torch.empty(n_win, dtype=torch.int32, **kw)
+        self.n_points = torch.empty(n_win, dtype=torch.int32, **kw)
+        self.h0_cap, self.h1_cap, self.n_win = h0_cap, h1_cap, n_win
+
+    def to_lists(self):
+        h0, c0 = self.h0.cpu().numpy(), self.c0.cpu().numpy()
+        h1, c1 = self.h1.cpu().numpy(), self.c1.cpu().numpy()
+        return _diagrams(h0, c0, self.h0_cap), _diagrams(h1, c1, self.h1_cap)
+
+
+def corr_dist_dev(win_t, dist_t=None, corr_t=None, ctx=None):
+    import torch
+    ctx = ctx or get_ctx()
+    assert win_t.is_cuda and win_t.dtype == torch.float64 and win_t.is_contiguous()
+    n_win, n_ch, n_t = win_t.shape
+    if dist_t is None:
+        dist_t = torch.empty((n_win, n_ch, n_ch), dtype=torch.float64, device=win_t.device)
+    ctx.check(ctx.lib.tda_corr_dist_batch_dev(ctx.h, _tp(win_t), n_win, n_ch, n_t, _tp(dist_t), _tp(corr_t), _stream()))
+    return dist_t
+
+
+def rips_dm_dev(dm_t, out=None, thresh=MAX_EDGE_LENGTH, symmetrise=True, h1_cap=DEFAULT_H1_CAP, ctx=None):
+    import torch
+    ctx = ctx or get_ctx()
+    assert dm_t.is_cuda and dm_t.dtype == torch.float64 and dm_t.is_contiguous()
+    n_win, n, _ = dm_t.shape
+    out = out or DeviceDiagrams(n_win, n, h1_cap, dm_t.device)
+    ctx.check(ctx.lib.tda_rips_dm_batch_dev(ctx.h, _tp(dm_t), n_win, n, float(thresh), int(bool(symmetrise)),
+                                            _tp(out.h0), out.h0_cap, _tp(out.c0), _tp(out.h1), out.h1_cap,
+                                            _tp(out.c1), _tp(out.status), _stream()))
+    return out
+
+
+def takens_rips_dev(win_t, tau_t, out=None, dim=3, subsample=2, thresh=MAX_EDGE_LENGTH, h1_cap=DEFAULT_H1_CAP,
+                    ctx=None):
+    import torch
+    ctx = ctx or get_ctx()
+    assert win_t.is_cuda and win_t.dtype == torch.float64 and win_t.is_contiguous()
+    assert tau_t.dtype == torch.int32 and tau_t.is_cuda
+    n_win, n_t = win_t.shape
+    out = out or DeviceDiagrams(n_win, _lib.MAX_POINTS, h1_cap, win_t.device)
+    ctx.check(ctx.lib.tda_takens_rips_batch_dev(ctx.h, _tp(win_t), _tp(tau_t), n_win, n_t, dim, subsample,
+                                                float(thresh), _tp(out.h0), out.h0_cap, _tp(out.c0), _tp(out.h1),
+                                                out.h1_cap, _tp(out.c1), _tp(out.n_points), _tp(out.status),
+                                                _stream()))
+    return out
+
+
+def tau_dev(win_t, max_lag=None, tau_t=None, ctx=None):
+    import torch
+    ctx = ctx or get_ctx()
+    n_win, n_t = win_t.shape
+    if tau_t is None:
+        tau_t = torch.empty(n_win, dtype=torch.int32, device=win_t.device)
+    ctx.check(ctx.lib.tda_tau_batch_dev(ctx.h, _tp(win_t), n_win, n_t, -1 if max_lag is None else int(max_lag),
+                                        _tp(tau_t), _stream()))
+    return tau_t
+
+
+def features_dev(rows_t, cnt_t, feat_t=None, ctx=None):
+    import torch
+    ctx = ctx or get_ctx()
+    n, cap, _ = rows_t.shape
+    if feat_t is None:
+        feat_t = torch.empty((n, _lib.N_FEATURES), dtype=torch.float64, device=rows_t.device)
+    ctx.check(ctx.lib.tda_features_batch_dev(ctx.h, _tp(rows_t), _tp(cnt_t), n, cap, _tp(feat_t), _stream()))
+    return feat_t
+
+
+def aggregate_dev(f0_t, f1_t, seg_off_t, out_t=None, ctx=None):
+    import torch
+    ctx = ctx or get_ctx()
+    n_seg = seg_off_t.numel() - 1
+    if out_t is None:
+        out_t = torch.empty((n_seg, 4 * _lib.N_FEATURES), dtype=torch.float64, device=f0_t.device)
+    ctx.check(ctx.lib.tda_aggregate_batch_dev(ctx.h, _tp(f0_t), _tp(f1_t), _tp(seg_off_t), n_seg, _tp(out_t),
+                                              _stream()))
+    return out_t
+
+
+def wasserstein_dev(rows_a, cnt_a, rows_b, cnt_b, idx_a=None, idx_b=None, out_t=None, status_t=None, ctx=None):
+    import torch
+    ctx = ctx or get_ctx()
+    n_pairs = rows_a.shape[0] if idx_a is None and idx_b is None else (idx_a if idx_a is not None else idx_b).numel()
+    if out_t is None:
+        out_t = torch.empty(n_pairs, dtype=torch.float64, device=rows_a.device)
+    if status_t is None:
+        status_t = torch.empty(n_pairs, dtype=torch.int32, device=rows_a.device)
+    ctx.check(ctx.lib.tda_wasserstein_batch_dev(ctx.h, _tp(rows_a), _tp(cnt_a), rows_a.shape[1], _tp(rows_b),
+                                                _tp(cnt_b), rows_b.shape[1], _tp(idx_a), _tp(idx_b), n_pairs,
+                                                _tp(out_t), _tp(status_t), _stream()))
+    return out_t, status_t

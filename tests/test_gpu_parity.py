@@ -1,0 +1,334 @@
+"""
+GPU parity tests: the HIP path, called through the C ABI (libtdaeeg.so), against the CPU
+oracle (oracle/tda_oracle.c + oracle/brute.py) on the same seeded inputs and against the
+golden vectors captured from the reference (tests/golden/reference_golden.npz).
+
+Bars: bit-exact for H0/H1 (birth, death) pairs (compared as sorted multisets of float32-exact
+values) and for every float64 stage whose operation order the oracle fixes (corr/dist, tau);
+Wasserstein within 1e-6 absolute (north_star), observed ~1e-12; features within 1e-12 relative.
+"""
+import numpy as np
+import pytest
+
+from oracle import brute, port
+from tda_eeg_audio_amd import engine, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _same_multiset(a, b):
+    return np.array_equal(brute.sort_rows(a), brute.sort_rows(b))
+
+
+# ------------------------------------------------------------------ corr -> dist
+def test_corr_dist_bit_exact_vs_oracle(ctx):
+    W = synth.eeg_windows(37, seed=7)
+    W[3, 5] = 1.25                       # zero-variance channel
+    W[4, 11] = W[4, 7]                   # duplicated channel
+    corr, dist = engine.corr_dist_batch(W, ctx=ctx)
+    oc, od = port.corr_dist_batch(W)
+    assert np.array_equal(dist, od)
+    assert np.array_equal(corr, oc)
+    assert np.all(dist[3, 5, np.arange(47) != 5] == np.sqrt(2.0))
+
+
+def test_corr_dist_vs_reference_golden(ctx, golden):
+    corr, dist = engine.corr_dist_batch(golden["cd_windows"], ctx=ctx)
+    assert np.abs(corr - golden["cd_corr"]).max() <= 1e-12
+    assert np.abs(dist - golden["cd_dist"]).max() <= 1e-7      # sqrt near r=1 amplifies 1e-16 -> 1e-8
+    off = ~np.eye(47, dtype=bool)
+    far = golden["cd_dist"][:, off] > 1e-3
+    assert np.abs(dist[:, off] - golden["cd_dist"][:, off])[far].max() <= 1e-12
+    # float32 cast (what ripser consumes) identical
+    assert np.array_equal(dist.astype(np.float32), golden["cd_dist"].astype(np.float32))
+
+
+def test_corr_dist_other_shapes(ctx):
+    rng = np.random.default_rng(3)
+    for n_ch, n_t in [(2, 5), (8, 64), (47, 500), (64, 100), (33, 51)]:
+        W = rng.standard_normal((3, n_ch, n_t))
+        corr, dist = engine.corr_dist_batch(W, ctx=ctx)
+        oc, od = port.corr_dist_batch(W)
+        assert np.array_equal(dist, od) and np.array_equal(corr, oc)
+
+
+# ------------------------------------------------------------------ Rips from distance matrices
+def test_rips_dm_known_answers(ctx):
+    sq = np.array([[0, 0], [1, 0], [1, 1], [0, 1]], float)
+    hexa = np.array([[np.cos(k * np.pi / 3), np.sin(k * np.pi / 3)] for k in range(6)])
+    tri = np.array([[0, 0], [1, 0], [0.3, 0.8]])
+
+    def dm(p):
+        return np.sqrt(((p[:, None] - p[None]) ** 2).sum(-1))
+
+    h0, h1, st = engine.rips_dm_batch(np.stack([dm(sq)]), ctx=ctx)
+    assert st[0] == 0
+    assert np.array_equal(h0[0], [[0, 1], [0, 1], [0, 1], [0, np.inf]])
+    assert np.array_equal(h1[0], np.array([[1.0, np.float32(np.sqrt(2.0))]], dtype=np.float64))
+    h0, h1, st = engine.rips_dm_batch(np.stack([dm(hexa)]), ctx=ctx)
+    assert len(h1[0]) == 1 and h1[0][0, 0] == np.float32(dm(hexa)[0, 1]) and h1[0][0, 1] == np.float32(np.sqrt(3.0))
+    h0, h1, st = engine.rips_dm_batch(np.stack([dm(tri)]), ctx=ctx)
+    assert len(h1[0]) == 0 and len(h0[0]) == 3
+    # 4-cycle with thresh below the diagonal: one essential H1 class; two clusters: 2 essential H0
+    h0, h1, st = engine.rips_dm_batch(np.stack([dm(sq)]), thresh=1.2, ctx=ctx)
+    assert np.array_equal(h1[0], [[1.0, np.inf]])
+    two = np.array([[0, 0], [0.1, 0], [5, 5], [5.1, 5]], float)
+    h0, h1, st = engine.rips_dm_batch(np.stack([dm(two)]), thresh=1.0, ctx=ctx)
+    assert np.isinf(h0[0][:, 1]).sum() == 2 and len(h0[0]) == 4
+    # duplicated points: zero-length merges are dropped
+    dup = np.array([[0, 0], [0, 0], [1, 0], [1, 0], [0, 1]], float)
+    h0, h1, st = engine.rips_dm_batch(np.stack([dm(dup)]), ctx=ctx)
+    assert len(h0[0]) == 5 - 1 - 2 + 1
+
+
+def test_rips_dm_config2_710_windows_bit_exact(ctx):
+    """BASELINE config 2: 710 EEG windows, 47x47, thresh 2.0."""
+    W = synth.eeg_windows(710, seed=42)
+    dist = engine.corr_dist_batch(W, want_corr=False, ctx=ctx)
+    h0, h1, st = engine.rips_dm_batch(dist, ctx=ctx)
+    assert not st.any()
+    stc, oh0, ok0, oh1, ok1 = port.rips_dm_batch(dist)
+    assert stc == 0
+    for w in range(710):
+        assert len(h0[w]) == ok0[w] and len(h1[w]) == ok1[w], w
+        assert _same_multiset(h0[w], oh0[w, :ok0[w]]), w
+        assert _same_multiset(h1[w], oh1[w, :ok1[w]]), w
+        assert len(h0[w]) == 47 and np.isinf(h0[w][-1, 1]) and np.all(np.diff(h0[w][:-1, 1]) >= 0)
+        assert np.all(np.diff(h1[w][:, 0]) <= 0)          # ripser order: descending birth
+
+
+def test_rips_dm_white_noise_and_random_metrics(ctx):
+    rng = np.random.default_rng(5)
+    mats = []
+    W = synth.eeg_windows(24, seed=9, kind="white")
+    mats += list(engine.corr_dist_batch(W, want_corr=False, ctx=ctx))
+    for _ in range(24):
+        d = rng.random((47, 47)); d = (d + d.T) / 2; np.fill_diagonal(d, 0); mats.append(d)
+    for _ in range(16):    # heavy ties
+        d = np.round(rng.random((47, 47)) * 6) / 6; d = (d + d.T) / 2; np.fill_diagonal(d, 0); mats.append(d)
+    mats = np.stack(mats)
+    for thresh in (2.0, 0.9, 0.4):
+        h0, h1, st = engine.rips_dm_batch(mats, thresh=thresh, h1_cap=512, ctx=ctx)
+        assert not st.any()
+        for w in range(len(mats)):
+            o = port.rips_dm(mats[w], thresh=thresh)
+            assert _same_multiset(h0[w], o[0]) and _same_multiset(h1[w], o[1]), (thresh, w)
+
+
+def test_rips_dm_against_brute_force_small(ctx):
+    rng = np.random.default_rng(11)
+    for n in (1, 2, 3, 5, 13, 30, 64):
+        mats = []
+        for _ in range(6):
+            d = rng.random((n, n)); d = (d + d.T) / 2; np.fill_diagonal(d, 0); mats.append(d)
+        mats = np.stack(mats)
+        for thresh in (2.0, 0.55):
+            h0, h1, st = engine.rips_dm_batch(mats, thresh=thresh, h1_cap=1024, ctx=ctx)
+            assert not st.any()
+            for w in range(len(mats)):
+                b0, b1 = brute.rips_brute(brute.eeg_prepare(mats[w]), thresh)
+                assert _same_multiset(h0[w], b0) and _same_multiset(h1[w], b1), (n, thresh, w)
+
+
+def test_rips_dm_larger_n_two_word_path(ctx):
+    rng = np.random.default_rng(12)
+    for n in (65, 100, 128):
+        X = rng.standard_normal((n, 3))
+        d = np.sqrt(((X[:, None] - X[None]) ** 2).sum(-1))
+        h0, h1, st = engine.rips_dm_batch(d[None], thresh=10.0, h1_cap=1024, ctx=ctx)
+        o = port.rips_dm(d, thresh=10.0)
+        assert st[0] == 0 and _same_multiset(h0[0], o[0]) and _same_multiset(h1[0], o[1]), n
+
+
+def test_rips_dm_symmetrise_semantics(ctx, golden):
+    D = golden["ep_in"]                                   # asymmetric, non-zero diagonal, one negative
+    keep = D.copy()
+    h0, h1, st = engine.rips_dm_batch(D[None], ctx=ctx)
+    assert np.array_equal(D, keep)                        # input untouched (utils.py:137)
+    o = port.rips_f32(golden["ep_dm"].astype(np.float32)) # the matrix the reference hands to ripser
+    assert _same_multiset(h0[0], o[0]) and _same_multiset(h1[0], o[1])
+
+
+def test_rips_class_overflow_is_reported_not_silent(ctx):
+    W = synth.eeg_windows(16, seed=3, kind="white")
+    dist = engine.corr_dist_batch(W, want_corr=False, ctx=ctx)
+    ctx.set_class_words(1, 1)
+    try:
+        h0, h1, st = engine.rips_dm_batch(dist, ctx=ctx)
+        for w in range(16):
+            o = port.rips_dm(dist[w])
+            if st[w] == 0:
+                assert _same_multiset(h1[w], o[1])
+            else:
+                assert st[w] & 2
+    finally:
+        ctx.set_class_words(2, 1)
+    ctx.set_class_words(4, 1)
+    try:
+        h0, h1, st = engine.rips_dm_batch(dist, ctx=ctx)
+        assert not st.any()
+        for w in range(16):
+            assert _same_multiset(h1[w], port.rips_dm(dist[w])[1])
+    finally:
+        ctx.set_class_words(2, 1)
+
+
+def test_rips_h1_truncation_flag(ctx):
+    W = synth.eeg_windows(4, seed=3, kind="white")
+    dist = engine.corr_dist_batch(W, want_corr=False, ctx=ctx)
+    h0, c0, h1, c1, st = engine.rips_dm_batch(dist, h1_cap=8, ctx=ctx, raw=True)
+    assert np.all(st & 1) and np.all(c1 > 8)
+    for w in range(4):
+        assert c1[w] == len(port.rips_dm(dist[w])[1])
+
+
+# ------------------------------------------------------------------ tau, Takens + Rips (audio)
+def test_tau_bit_exact(ctx, golden):
+    wins, _ = synth.audio_windows_all_bands(40, seed=5)
+    tau = engine.tau_batch(wins, max_lag=125, ctx=ctx)
+    ref = np.array([port.compute_tau(w, 125) for w in wins])
+    assert np.array_equal(tau, ref)
+    assert np.array_equal(engine.tau_batch(golden["tau_signals"], max_lag=125, ctx=ctx), golden["tau_values"])
+    assert engine.tau_batch(np.full((1, 250), 1.5), max_lag=125, ctx=ctx)[0] == golden["tau_const"][0]
+    ramp = np.arange(250.0)[None]
+    assert engine.tau_batch(ramp, max_lag=125, ctx=ctx)[0] == golden["tau_ramp"][0]
+    assert engine.tau_batch(ramp, max_lag=None, ctx=ctx)[0] == golden["tau_ramp"][1]
+
+
+def test_takens_rips_config4_bit_exact(ctx):
+    """BASELINE config 4 shape: band-limited windows -> tau -> Takens(3, tau, 2) -> Rips."""
+    wins, band = synth.audio_windows_all_bands(30, seed=42)
+    tau = engine.tau_batch(wins, max_lag=125, ctx=ctx)
+    h0, h1, npts, st = engine.takens_rips_batch(wins, tau, ctx=ctx)
+    assert not st.any()
+    for w in range(len(wins)):
+        (o0, o1), P = port.audio_persistence(wins[w], int(tau[w]))
+        assert npts[w] == P
+        assert _same_multiset(h0[w], o0) and _same_multiset(h1[w], o1), (w, int(tau[w]))
+        assert len(h0[w]) <= P
+
+
+def test_takens_rips_edge_cases(ctx):
+    wins = synth.audio_windows(6, "delta", seed=1)
+    tau = np.array([124, 125, 200, 1, 100, 62], np.int32)     # P = 1, 0, 0, 124, 25, 63
+    h0, h1, npts, st = engine.takens_rips_batch(wins, tau, ctx=ctx)
+    assert list(npts) == [1, 0, 0, 124, 25, 63]
+    for w in (0, 1, 2):                                        # utils.py:125-126
+        assert st[w] == 4 and np.array_equal(h0[w], [[0, 0]]) and np.array_equal(h1[w], [[0, 0]])
+    for w in (3, 4, 5):
+        (o0, o1), P = port.audio_persistence(wins[w], int(tau[w]))
+        assert st[w] == 0 and _same_multiset(h0[w], o0) and _same_multiset(h1[w], o1)
+    # constant window: zero range -> 1 (utils.py:129); all points coincide
+    const = np.full((1, 250), 0.75)
+    h0, h1, npts, st = engine.takens_rips_batch(const, np.array([2], np.int32), ctx=ctx)
+    assert np.array_equal(h0[0], [[0, np.inf]]) and len(h1[0]) == 0
+
+
+def test_cloud_rips_matches_reference_preprocessing(ctx, golden):
+    """compute_audio_persistence(point_cloud): normalisation pinned by the recording stub."""
+    for name in ("delta", "theta", "alpha", "beta", "gamma"):
+        pc = golden["tk_pc_" + name]
+        h0, h1, st = engine.cloud_rips_batch(pc[None], ctx=ctx)
+        # oracle fed with the reference's own pc_norm and sklearn's own distance matrix
+        o = port.rips_f32(golden["pd_" + name].astype(np.float32))
+        assert st[0] == 0 and _same_multiset(h0[0], o[0]) and _same_multiset(h1[0], o[1]), name
+
+
+# ------------------------------------------------------------------ features
+def test_features_vs_reference_golden_and_oracle(ctx, golden):
+    names = ["mixed", "single", "empty_finite", "zero_pers", "f32vals", "big"]
+    rows, cnt = engine.pack_diagrams([golden["ef_in_" + k] for k in names])
+    feat = engine.features_batch(rows, cnt, ctx=ctx)
+    for i, k in enumerate(names):
+        ref = golden["ef_out_" + k]
+        assert np.allclose(feat[i], ref, rtol=1e-12, atol=1e-15), k
+        assert np.array_equal(feat[i, :10], ref[:10]), k          # everything but the entropy (log) bit-exact
+    rows, cnt = engine.pack_diagrams([np.zeros((0, 2))])
+    assert np.array_equal(engine.features_batch(rows, cnt, ctx=ctx)[0], np.zeros(11))
+
+
+def test_features_and_aggregate_on_real_diagrams(ctx):
+    W = synth.eeg_windows(78, seed=21)
+    dist = engine.corr_dist_batch(W, want_corr=False, ctx=ctx)
+    h0, c0, h1, c1, st = engine.rips_dm_batch(dist, ctx=ctx, raw=True)
+    f0 = engine.features_batch(h0, c0, ctx=ctx)
+    f1 = engine.features_batch(h1, c1, ctx=ctx)
+    for w in range(78):
+        assert np.allclose(f0[w], port.features(h0[w, :c0[w]]), rtol=1e-12, atol=0)
+        assert np.allclose(f1[w], port.features(h1[w, :c1[w]]), rtol=1e-12, atol=0)
+    seg = np.array([0, 39, 78], np.int32)
+    agg = engine.aggregate_batch(f0, f1, seg, ctx=ctx)
+    for s in range(2):
+        a, b = seg[s], seg[s + 1]
+        for f in range(11):
+            exp = [np.mean(f0[a:b, f]), np.std(f0[a:b, f]), np.mean(f1[a:b, f]), np.std(f1[a:b, f])]
+            assert np.array_equal(agg[s, 4 * f:4 * f + 4], exp), (s, f)
+
+
+# ------------------------------------------------------------------ Wasserstein
+def test_wasserstein_known_answers(ctx):
+    A = np.array([[0.0, 1.0]]); B = np.array([[0.0, 2.0]])
+    E = np.zeros((0, 2))
+    pts = np.array([[0.1, 0.9], [0.2, 0.5], [0.0, 0.3]])
+    ra, ca = engine.pack_diagrams([A, A, pts, E, pts])
+    rb, cb = engine.pack_diagrams([B, A, E, E, pts[::-1]])
+    out, st = engine.wasserstein_batch(ra, ca, rb, cb, ctx=ctx, want_status=True)
+    assert not st.any()
+    assert abs(out[0] - 1.0) < 1e-12
+    assert out[1] == 0.0
+    assert abs(out[2] - ((pts[:, 1] - pts[:, 0]) / np.sqrt(2)).sum()) < 1e-12
+    assert out[3] == 0.0
+    assert abs(out[4]) < 1e-12
+
+
+def test_wasserstein_vs_persim_restatement_and_bruteforce(ctx):
+    rng = np.random.default_rng(8)
+    As, Bs = [], []
+    for _ in range(200):
+        As.append(np.sort(rng.random((int(rng.integers(0, 60)), 2)), axis=1))
+        Bs.append(np.sort(rng.random((int(rng.integers(0, 130)), 2)), axis=1))
+    ra, ca = engine.pack_diagrams(As, cap=64); rb, cb = engine.pack_diagrams(Bs, cap=130)
+    out, st = engine.wasserstein_batch(ra, ca, rb, cb, ctx=ctx, want_status=True)
+    assert not st.any()
+    ref = np.array([brute.safe_wasserstein_oracle(a, b) for a, b in zip(As, Bs)])
+    assert np.abs(out - ref).max() < 1e-6            # north_star tolerance
+    assert np.abs(out - ref).max() < 1e-10           # what is actually achieved
+    # symmetry
+    out2 = engine.wasserstein_batch(rb, cb, ra, ca, ctx=ctx)
+    assert np.abs(out - out2).max() < 1e-10
+    # exhaustive optimum for tiny diagrams
+    As = [np.sort(rng.random((int(rng.integers(1, 5)), 2)), axis=1) for _ in range(20)]
+    Bs = [np.sort(rng.random((int(rng.integers(1, 5)), 2)), axis=1) for _ in range(20)]
+    ra, ca = engine.pack_diagrams(As); rb, cb = engine.pack_diagrams(Bs)
+    out = engine.wasserstein_batch(ra, ca, rb, cb, ctx=ctx)
+    for i in range(20):
+        assert abs(out[i] - brute.wasserstein_bruteforce(As[i], Bs[i])) < 1e-9
+
+
+def test_wasserstein_infinite_rows_ignored_and_index_pairs(ctx):
+    A = np.array([[0.0, 0.5], [0.0, np.inf], [0.1, 0.7]])
+    B = np.array([[0.0, np.inf]])
+    C_ = np.array([[0.2, 0.9], [0.3, 0.35]])
+    ra, ca = engine.pack_diagrams([A, B, C_])
+    idx_a = np.array([0, 0, 1, 2], np.int32); idx_b = np.array([1, 2, 2, 0], np.int32)
+    out = engine.wasserstein_batch(ra, ca, ra, ca, idx_a, idx_b, ctx=ctx)
+    dg = [A, B, C_]
+    for k in range(4):
+        assert abs(out[k] - brute.safe_wasserstein_oracle(dg[idx_a[k]], dg[idx_b[k]])) < 1e-10
+
+
+def test_end_to_end_h0_h1_wasserstein_on_pipeline_diagrams(ctx):
+    """cmp:88-96 on synthetic data: EEG diagrams vs audio diagrams, H0 and H1."""
+    n = 60
+    W = synth.eeg_windows(n, seed=77)
+    aw = synth.audio_windows(n, "beta", seed=78)
+    dist = engine.corr_dist_batch(W, want_corr=False, ctx=ctx)
+    e0, ec0, e1, ec1, est = engine.rips_dm_batch(dist, ctx=ctx, raw=True)
+    tau = engine.tau_batch(aw[:1], max_lag=125, ctx=ctx)[0]
+    a0, ac0, a1, ac1, npts, ast = engine.takens_rips_batch(aw, tau, ctx=ctx, raw=True)
+    w0 = engine.wasserstein_batch(e0, ec0, a0, ac0, ctx=ctx)
+    w1 = engine.wasserstein_batch(e1, ec1, a1, ac1, ctx=ctx)
+    for w in range(n):
+        r0 = brute.safe_wasserstein_oracle(e0[w, :ec0[w]], a0[w, :ac0[w]])
+        r1 = brute.safe_wasserstein_oracle(e1[w, :ec1[w]], a1[w, :ac1[w]])
+        assert abs(w0[w] - r0) < 1e-6 and abs(w1[w] - r1) < 1e-6, (w, w0[w], r0, w1[w], r1)
