@@ -628,7 +628,10 @@ tda_status launch_rips_dm(tda_ctx* ctx, const double* dm, int n_win, int n, doub
         else if (W == 2) rc = launch_dm_t<1, 2>(ctx, dm, n_win, n, th, symmetrise, out, st);
         else rc = launch_dm_t<1, 4>(ctx, dm, n_win, n, th, symmetrise, out, st);
     } else {
-        if (W == 1) rc = launch_dm_t<2, 1>(ctx, dm, n_win, n, th, symmetrise, out, st);
+        // 128 classes only while [psi | ord | skey] still fits the 160 KiB LDS (n <= 112)
+        const int E = n * (n - 1) / 2;
+        const bool fits2 = (size_t)E * 16 + (size_t)E * 6 + 64 <= 160 * 1024;
+        if (W == 1 || !fits2) rc = launch_dm_t<2, 1>(ctx, dm, n_win, n, th, symmetrise, out, st);
         else rc = launch_dm_t<2, 2>(ctx, dm, n_win, n, th, symmetrise, out, st);
     }
     if (rc != TDA_OK) return rc;
