@@ -1,0 +1,175 @@
+#!/usr/bin/env python3
+"""
+bench.py -- headline benchmark: windows/sec end-to-end (dist -> Rips H0/H1 -> Wasserstein),
+47-channel EEG, on N MI355X (BASELINE.json `metric`).
+
+A step = ONE pass of the per-window hot path (tda_eeg_audio_amd/pipeline.py::run_step, the
+batched counterpart of scripts/tda_eeg_audio_comparison.py:77-122) over one batch of synthetic
+input already resident in HBM: per window corr->dist, Rips(EEG 47x47), Takens+Rips(audio),
+Wasserstein H0 and H1, H1 features, and the per-recording reductions.  Workload at N=1 =
+BASELINE.json configs[1]: 710 EEG windows of one band (+ the 710 matching audio windows).
+N>1: every rank gets its own 710 windows (weak scaling); the only collective is one all-gather
+of the per-recording result rows (RCCL over xGMI), inside the timed region.
+
+Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (largest share of the
+step), with its average launch duration measured live with events on the launch stream.
+`cpu_baseline` times the CPU oracle (oracle/tda_oracle.c, kind "port", 1 core) on a bounded
+sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+# ALGORITHMIC HBM bytes per unit of work of each kernel
+ALG_BYTES = {
+    "corr_dist": 47 * 250 * 8 + 47 * 47 * 8,          # window in, distance matrix out (no corr copy)
+    "rips_eeg": 47 * 47 * 8 + 1100,                   # 18.7 KB/window from the stored f64 matrix
+    "tau": 250 * 8 + 4,
+    "rips_audio": 250 * 8 + 4 + 1500,                 # ~3.5 KB/window
+    "wasserstein_h0": 2700 + 8,                       # <= 2.7 KB/pair
+    "wasserstein_h1": 2700 + 8,
+    "features": 3 * (1100 + 88),
+    "aggregate": 2 * 22 * 8,
+}
+HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--windows", type=int, default=710, help="windows per GPU per step (configs[1] = 710)")
+    ap.add_argument("--windows-per-recording", type=int, default=15, help="cmp:39 MAX_WINDOWS")
+    ap.add_argument("--band", default="beta")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg")
+    ap.add_argument("--no-cpu", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from tda_eeg_audio_amd import _lib, pipeline, synth
+    from tda_eeg_audio_amd import dist as tdist
+
+    rank, world, local = tdist.init_from_env()
+    assert world == args.gpus or world == 1, f"WORLD_SIZE={world} but --gpus {args.gpus}"
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    ctx = _lib.get_ctx(local)
+
+    n_win = args.windows
+    wpr = args.windows_per_recording
+    seg = list(range(0, n_win, wpr)) + [n_win]
+    seg_off = np.array(seg, np.int32)
+    n_seg = len(seg_off) - 1
+    # synthetic data of the named shape; each rank its own recordings (weak scaling)
+    eeg = synth.eeg_windows(n_win, seed=42 + 100000 * rank, windows_per_recording=wpr)
+    aud = synth.audio_windows(n_win, args.band, seed=4242 + 100000 * rank)
+    eeg_t = torch.from_numpy(eeg).to(device)
+    aud_t = torch.from_numpy(aud).to(device)
+    ws = pipeline.Workspace(n_win, seg_off, device)
+    shards = [np.arange(r * n_seg, (r + 1) * n_seg) for r in range(world)]
+
+    def step(timers=None):
+        res = pipeline.run_step(eeg_t, aud_t, ws, ctx=ctx, timers=timers)
+        if world > 1:
+            return tdist.all_gather_rows(res, shards[rank], shards, world * n_seg)
+        return res
+
+    for _ in range(args.warmup):
+        out = step()
+    torch.cuda.synchronize()
+    if not bool(((ws.eeg.status == 0) & ((ws.aud.status & ~4) == 0) & (ws.ws0 == 0) & (ws.ws1 == 0)).all()):
+        raise SystemExit("bench: a window reported a non-zero status (overflow / not converged)")
+
+    stage_ms = {s: 0.0 for s in pipeline.STAGES}
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ev_log = []
+    for _ in range(args.steps):
+        timers = {s: (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                  for s in pipeline.STAGES}
+        out = step(timers)          # events are recorded on the launch stream, read after the loop
+        ev_log.append(timers)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    for evs in ev_log:
+        for s, (a, b) in evs.items():
+            stage_ms[s] += a.elapsed_time(b)
+    stage_ms = {s: v / args.steps for s, v in stage_ms.items()}
+
+    if rank == 0:
+        total_windows = world * n_win * args.steps
+        value = total_windows / dt
+        dom = max(stage_ms, key=stage_ms.get)
+        achieved = ALG_BYTES[dom] * n_win / (stage_ms[dom] * 1e-3) / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get(dom)
+            except Exception:
+                traffic = None
+        line = {
+            "metric": "windows/sec end-to-end (dist->Rips H0/H1->Wasserstein), 47-ch EEG",
+            "value": value, "unit": "windows/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"configs[1]: {n_win} EEG windows (47x250 f64) x 1 band ({args.band}) per GPU, "
+                                   f"+ {n_win} audio windows (250 f64); corr->dist->Rips H0/H1 (EEG 47 pts, audio "
+                                   f"Takens dim 3 sub 2), Wasserstein H0+H1, H1 features, per-recording "
+                                   f"({wpr} windows) reductions" + ("; one all-gather of result rows" if world > 1 else ""),
+                       "windows_per_gpu": n_win, "thresh": 2.0, "parallelism": f"recordings sharded x{world}"},
+            "stage_ms": {s: round(v, 4) for s, v in stage_ms.items()},
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "note": "irregular integer work in LDS/registers; HBM fraction is small by construction"},
+        }
+        if not args.no_cpu:
+            line["cpu_baseline"] = cpu_baseline(eeg, aud, seg_off, args.cpu_seconds)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(eeg, aud, seg_off, budget_s):
+    """CPU oracle (C restatement of the ripser-class algorithm + persim's assignment), 1 core,
+    timed on whole recordings of the SAME batch until ~budget_s seconds are spent."""
+    from tda_eeg_audio_amd import pipeline
+    done = 0
+    t0 = time.perf_counter()
+    s = 0
+    n_seg = len(seg_off) - 1
+    while True:
+        a, b = int(seg_off[s % n_seg]), int(seg_off[s % n_seg + 1])
+        pipeline.reference_step_cpu(eeg[a:b], aud[a:b], np.array([0, b - a]))
+        done += b - a
+        s += 1
+        el = time.perf_counter() - t0
+        if el >= budget_s:
+            break
+    return {"value": done / el, "unit": "windows/s", "cores": 1, "kind": "port",
+            "sample": f"{done} windows ({s} recordings, cycling through the batch of {int(seg_off[-1])}), {el:.1f} s, oracle/tda_oracle.c "
+                      f"(gcc -O2), same end-to-end unit"}
+
+
+if __name__ == "__main__":
+    main()

@@ -156,6 +156,15 @@ tda_status tda_aggregate_batch_dev(tda_ctx* ctx, const double* feat_h0, const do
 tda_status tda_aggregate_batch(tda_ctx* ctx, const double* feat_h0, const double* feat_h1,
                                const int* seg_off, int n_seg, int n_total, double* out);
 
+/* ---- np.nanmean over the windows of each (recording, band) group ----------------
+ * replaces np.nanmean(wass_h0) / np.nanmean(vals) (scripts/tda_eeg_audio_comparison.py:117-118,
+ * scripts/matched_vs_mismatched.py:95).  x: (n_total) float64; seg_off: (n_seg+1) int32.
+ * Empty or all-NaN groups give NaN.                                                    */
+tda_status tda_segment_nanmean_dev(tda_ctx* ctx, const double* x, const int* seg_off, int n_seg,
+                                   double* out, void* stream);
+tda_status tda_segment_nanmean(tda_ctx* ctx, const double* x, const int* seg_off, int n_seg,
+                               int n_total, double* out);
+
 /* ---- Wasserstein distance between diagrams ------------------------------------
  * replaces safe_wasserstein (scripts/utils.py:180-191) -> persim.wasserstein
  * (order 1, Euclidean ground metric, diagonal cost (d-b)/sqrt 2).

@@ -133,6 +133,14 @@ tda_status tda_aggregate_batch_dev(tda_ctx* ctx, const double* feat_h0, const do
     return launch_aggregate(ctx, feat_h0, feat_h1, seg_off, n_seg, out, (hipStream_t)stream);
 }
 
+tda_status tda_segment_nanmean_dev(tda_ctx* ctx, const double* x, const int* seg_off, int n_seg, double* out,
+                                   void* stream)
+{
+    CHECK_CTX(ctx); CHECK_NONNEG(ctx, n_seg);
+    if (n_seg) { CHECK_PTR(ctx, x); CHECK_PTR(ctx, seg_off); CHECK_PTR(ctx, out); }
+    return launch_nanmean(ctx, x, seg_off, n_seg, out, (hipStream_t)stream);
+}
+
 tda_status tda_wasserstein_batch_dev(tda_ctx* ctx, const double* dgm_a, const int* cnt_a, int cap_a,
                                      const double* dgm_b, const int* cnt_b, int cap_b, const int* idx_a,
                                      const int* idx_b, int n_pairs, double* out, int* status, void* stream)
@@ -327,6 +335,22 @@ tda_status tda_aggregate_batch(tda_ctx* ctx, const double* feat_h0, const double
     s.add((void**)&d_out, nullptr, out, (size_t)n_seg * 4 * TDA_N_FEATURES * 8);
     RET_IF(s.upload());
     RET_IF(tda_aggregate_batch_dev(ctx, d0, d1, d_off, n_seg, d_out, nullptr));
+    return s.download();
+}
+
+tda_status tda_segment_nanmean(tda_ctx* ctx, const double* x, const int* seg_off, int n_seg, int n_total, double* out)
+{
+    CHECK_CTX(ctx); CHECK_NONNEG(ctx, n_seg); CHECK_NONNEG(ctx, n_total);
+    if (n_seg == 0) return TDA_OK;
+    CHECK_PTR(ctx, x); CHECK_PTR(ctx, seg_off); CHECK_PTR(ctx, out);
+    TDA_HIP(ctx, hipSetDevice(ctx->device));
+    Stage s(ctx);
+    double *d_x, *d_out; int* d_off;
+    s.add((void**)&d_x, x, nullptr, (size_t)n_total * 8);
+    s.add((void**)&d_off, seg_off, nullptr, (size_t)(n_seg + 1) * 4);
+    s.add((void**)&d_out, nullptr, out, (size_t)n_seg * 8);
+    RET_IF(s.upload());
+    RET_IF(tda_segment_nanmean_dev(ctx, d_x, d_off, n_seg, d_out, nullptr));
     return s.download();
 }
 

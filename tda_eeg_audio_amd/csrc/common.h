@@ -69,5 +69,6 @@ tda_status launch_rips_cloud(tda_ctx*, const double* win_or_pc, const int* tau_o
 tda_status launch_tau(tda_ctx*, const double*, int, int, int, int*, hipStream_t);
 tda_status launch_features(tda_ctx*, const double*, const int*, int, int, double*, hipStream_t);
 tda_status launch_aggregate(tda_ctx*, const double*, const double*, const int*, int, double*, hipStream_t);
+tda_status launch_nanmean(tda_ctx*, const double*, const int*, int, double*, hipStream_t);
 tda_status launch_wasserstein(tda_ctx*, const double*, const int*, int, const double*, const int*, int, const int*,
                               const int*, int, double*, int*, hipStream_t);

@@ -195,6 +195,32 @@ aggregate_kernel(const double* __restrict__ f0, const double* __restrict__ f1, c
 }
 
 // ---------------------------------------------------------------------------------
+// np.nanmean over the windows of each (recording, band) group  (cmp:117-118, mvm:95)
+// one lane per segment; sums follow numpy's pairwise tree over the non-NaN values
+// ---------------------------------------------------------------------------------
+__global__ void __launch_bounds__(64)
+nanmean_kernel(const double* __restrict__ x, const int* __restrict__ seg_off, int n_seg, double* __restrict__ out)
+{
+    const int seg = blockIdx.x * 64 + threadIdx.x;
+    if (seg >= n_seg) return;
+    const int s0 = seg_off[seg], s1 = seg_off[seg + 1];
+    // np.nanmean: NaNs replaced by 0, sum / count of non-NaN; all-NaN (or empty) -> NaN
+    int cnt = 0;
+    for (int i = s0; i < s1; ++i) cnt += (x[i] == x[i]) ? 1 : 0;
+    auto val = [=](int i) { const double v = x[s0 + i]; return v == v ? v : 0.0; };
+    const double sum = np_pairwise_fn(val, 0, s1 - s0);
+    out[seg] = cnt > 0 ? sum / (double)cnt : __longlong_as_double(0x7ff8000000000000ll);
+}
+
+tda_status launch_nanmean(tda_ctx* ctx, const double* x, const int* seg_off, int n_seg, double* out, hipStream_t st)
+{
+    if (n_seg == 0) return TDA_OK;
+    hipLaunchKernelGGL(nanmean_kernel, dim3((n_seg + 63) / 64), dim3(64), 0, st, x, seg_off, n_seg, out);
+    TDA_HIP(ctx, hipGetLastError());
+    return TDA_OK;
+}
+
+// ---------------------------------------------------------------------------------
 tda_status launch_tau(tda_ctx* ctx, const double* win, int n_win, int n_t, int max_lag, int* tau, hipStream_t st)
 {
     if (n_win == 0) return TDA_OK;

@@ -125,6 +125,14 @@ def aggregate_batch(feat_h0, feat_h1, seg_off, ctx=None):
     return out
 
 
+def segment_nanmean(x, seg_off, ctx=None):
+    ctx = ctx or get_ctx()
+    x = f64(x); off = i32(seg_off)
+    out = np.empty(len(off) - 1)
+    ctx.check(ctx.lib.tda_segment_nanmean(ctx.h, ptr(x), ptr(off), len(off) - 1, x.shape[0], ptr(out)))
+    return out
+
+
 def wasserstein_batch(rows_a, cnt_a, rows_b, cnt_b, idx_a=None, idx_b=None, ctx=None, want_status=False):
     ctx = ctx or get_ctx()
     ra = f64(rows_a); rb = f64(rows_b); ca = i32(cnt_a); cb = i32(cnt_b)
@@ -240,6 +248,16 @@ def aggregate_dev(f0_t, f1_t, seg_off_t, out_t=None, ctx=None):
         out_t = torch.empty((n_seg, 4 * _lib.N_FEATURES), dtype=torch.float64, device=f0_t.device)
     ctx.check(ctx.lib.tda_aggregate_batch_dev(ctx.h, _tp(f0_t), _tp(f1_t), _tp(seg_off_t), n_seg, _tp(out_t),
                                               _stream()))
+    return out_t
+
+
+def segment_nanmean_dev(x_t, seg_off_t, out_t=None, ctx=None):
+    import torch
+    ctx = ctx or get_ctx()
+    n_seg = seg_off_t.numel() - 1
+    if out_t is None:
+        out_t = torch.empty(n_seg, dtype=torch.float64, device=x_t.device)
+    ctx.check(ctx.lib.tda_segment_nanmean_dev(ctx.h, _tp(x_t), _tp(seg_off_t), n_seg, _tp(out_t), _stream()))
     return out_t
 
 

@@ -1,0 +1,127 @@
+"""
+pipeline.py -- the end-to-end per-window unit of the reference, batched on one GPU.
+
+Counterpart of the hot loop of process_recording (scripts/tda_eeg_audio_comparison.py:77-122):
+for every selected window  corr->dist (nb2:198-207) -> Rips(EEG) (cmp:93) ; tau once per
+recording-band from its first selected window (cmp:83) -> Takens -> Rips(audio) (cmp:89-92) ->
+Wasserstein H0 and H1 (cmp:95-96) -> features of the H1 diagrams (cmp:98-99); then per
+recording-band np.nanmean of the distances (cmp:117-118) and the mean/std feature aggregation of
+process_file_features (scripts/tda_eeg_classification_v2.py:429-436).
+
+Everything stays in HBM; each stage is one C-ABI launch on torch's current stream.  torch is
+only the allocator / stream owner here.
+"""
+import numpy as np
+
+from . import engine
+
+RESULT_COLS = 4 + 44      # [w_h0, w_h1, tau, n_windows] + 44 aggregated EEG features per recording-band
+
+
+class Workspace:
+    """Pre-allocated device buffers for a batch of n_win windows grouped into recordings."""
+
+    def __init__(self, n_win, seg_off, device, n_ch=47, h1_cap=engine.DEFAULT_H1_CAP):
+        import torch
+        self.n_win, self.device = n_win, device
+        seg_off = np.asarray(seg_off, np.int32)
+        assert seg_off[0] == 0 and seg_off[-1] == n_win
+        self.n_seg = len(seg_off) - 1
+        self.seg_off = torch.from_numpy(seg_off).to(device)
+        rec_id = np.repeat(np.arange(self.n_seg), np.diff(seg_off))
+        self.rec_id = torch.from_numpy(rec_id.astype(np.int64)).to(device)
+        self.first_idx = torch.from_numpy(seg_off[:-1].astype(np.int64)).to(device)
+        f64 = dict(dtype=torch.float64, device=device)
+        self.dist = torch.empty((n_win, n_ch, n_ch), **f64)
+        self.eeg = engine.DeviceDiagrams(n_win, n_ch, h1_cap, device)
+        self.aud = engine.DeviceDiagrams(n_win, 128, h1_cap, device)
+        self.tau_seg = torch.empty(self.n_seg, dtype=torch.int32, device=device)
+        self.w0 = torch.empty(n_win, **f64); self.w1 = torch.empty(n_win, **f64)
+        self.ws0 = torch.empty(n_win, dtype=torch.int32, device=device)
+        self.ws1 = torch.empty(n_win, dtype=torch.int32, device=device)
+        self.fe0 = torch.empty((n_win, 11), **f64); self.fe1 = torch.empty((n_win, 11), **f64)
+        self.fa1 = torch.empty((n_win, 11), **f64)
+        self.result = torch.empty((self.n_seg, RESULT_COLS), **f64)
+        self.n_win_seg = torch.from_numpy(np.diff(seg_off).astype(np.float64)).to(device)
+
+
+def run_step(eeg_win, audio_win, ws, ctx=None, max_lag=125, timers=None):
+    """One pass of the hot path over the batch.  eeg_win (n_win,47,250) f64, audio_win (n_win,250)
+    f64, both resident in HBM.  Returns ws.result (n_seg, 48).  `timers`: optional dict of
+    (start,end) torch.cuda.Event pairs per stage, recorded on the launch stream."""
+    import torch
+
+    def stage(name, fn):
+        if timers is None:
+            return fn()
+        s, e = timers[name]
+        s.record()
+        r = fn()
+        e.record()
+        return r
+
+    stage("corr_dist", lambda: engine.corr_dist_dev(eeg_win, ws.dist, None, ctx=ctx))
+    stage("rips_eeg", lambda: engine.rips_dm_dev(ws.dist, ws.eeg, ctx=ctx))
+    # tau from the first selected window of each recording-band (cmp:83), broadcast to its windows
+    first = audio_win.index_select(0, ws.first_idx)
+    stage("tau", lambda: engine.tau_dev(first, max_lag, ws.tau_seg, ctx=ctx))
+    tau_w = ws.tau_seg.index_select(0, ws.rec_id)
+    stage("rips_audio", lambda: engine.takens_rips_dev(audio_win, tau_w, ws.aud, ctx=ctx))
+    stage("wasserstein_h0", lambda: engine.wasserstein_dev(ws.eeg.h0, ws.eeg.c0, ws.aud.h0, ws.aud.c0,
+                                                           out_t=ws.w0, status_t=ws.ws0, ctx=ctx))
+    stage("wasserstein_h1", lambda: engine.wasserstein_dev(ws.eeg.h1, ws.eeg.c1, ws.aud.h1, ws.aud.c1,
+                                                           out_t=ws.w1, status_t=ws.ws1, ctx=ctx))
+
+    def feats():
+        engine.features_dev(ws.eeg.h0, ws.eeg.c0, ws.fe0, ctx=ctx)
+        engine.features_dev(ws.eeg.h1, ws.eeg.c1, ws.fe1, ctx=ctx)
+        engine.features_dev(ws.aud.h1, ws.aud.c1, ws.fa1, ctx=ctx)
+    stage("features", feats)
+
+    # per recording-band reductions (strided column views are not contiguous: reduce into temporaries)
+    def agg():
+        m0 = engine.segment_nanmean_dev(ws.w0, ws.seg_off, ctx=ctx)
+        m1 = engine.segment_nanmean_dev(ws.w1, ws.seg_off, ctx=ctx)
+        a = engine.aggregate_dev(ws.fe0, ws.fe1, ws.seg_off, ctx=ctx)
+        ws.result[:, 0] = m0
+        ws.result[:, 1] = m1
+        ws.result[:, 2] = ws.tau_seg.to(torch.float64)
+        ws.result[:, 3] = ws.n_win_seg
+        ws.result[:, 4:] = a
+    stage("aggregate", agg)
+    return ws.result
+
+
+STAGES = ["corr_dist", "rips_eeg", "tau", "rips_audio", "wasserstein_h0", "wasserstein_h1", "features", "aggregate"]
+
+
+def reference_step_cpu(eeg_win, audio_win, seg_off, max_lag=125):
+    """The same unit on the CPU ORACLE -- test/benchmark infrastructure only (imports oracle/)."""
+    from oracle import port
+    n_win = eeg_win.shape[0]
+    seg_off = np.asarray(seg_off)
+    res = np.empty((len(seg_off) - 1, RESULT_COLS))
+    for s in range(len(seg_off) - 1):
+        a, b = seg_off[s], seg_off[s + 1]
+        tau = port.compute_tau(audio_win[a], max_lag)
+        w0, w1, f0, f1 = [], [], [], []
+        for w in range(a, b):
+            _, d = port.corr_dist(eeg_win[w])
+            e = port.rips_dm(d)
+            (au, P) = port.audio_persistence(audio_win[w], tau)
+            w0.append(port.wasserstein(_clean(e[0]), _clean(au[0])))
+            w1.append(port.wasserstein(_clean(e[1]), _clean(au[1])))
+            f0.append(port.features(e[0])); f1.append(port.features(e[1]))
+            port.features(au[1])
+        f0 = np.array(f0); f1 = np.array(f1)
+        res[s, 0] = np.nanmean(w0); res[s, 1] = np.nanmean(w1); res[s, 2] = tau; res[s, 3] = b - a
+        for f in range(11):
+            res[s, 4 + 4 * f: 8 + 4 * f] = [f0[:, f].mean(), f0[:, f].std(), f1[:, f].mean(), f1[:, f].std()]
+    return res
+
+
+def _clean(d):
+    d = np.asarray(d).reshape(-1, 2)
+    m = np.isfinite(d).all(axis=1)
+    d = d[m]
+    return d if len(d) else np.zeros((1, 2))
