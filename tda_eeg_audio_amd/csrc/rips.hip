@@ -39,6 +39,32 @@
         __builtin_amdgcn_wave_barrier();                       \
     } while (0)
 
+// ---- optional phase profiling (make PROFILE=1): cycle sums per phase over all windows ----
+#ifdef TDA_PROFILE
+__device__ unsigned long long g_prof[16];
+#define PROF_BEGIN() unsigned long long prof_t0 = clock64()
+#define PROF_MARK(i)                                                       \
+    do {                                                                   \
+        unsigned long long prof_t1 = clock64();                            \
+        if (lane_id() == 0) atomicAdd(&g_prof[i], prof_t1 - prof_t0);      \
+        prof_t0 = prof_t1;                                                 \
+    } while (0)
+#define PROF_COUNT(i, v) do { if (lane_id() == 0) atomicAdd(&g_prof[i], (unsigned long long)(v)); } while (0)
+extern "C" __attribute__((visibility("default"))) int tda_profile_read(unsigned long long* out, int reset)
+{
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_prof), sizeof(unsigned long long) * 16) != hipSuccess) return 1;
+    if (reset) {
+        unsigned long long z[16] = {0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_prof), z, sizeof(z)) != hipSuccess) return 1;
+    }
+    return 0;
+}
+#else
+#define PROF_BEGIN() do {} while (0)
+#define PROF_MARK(i) do {} while (0)
+#define PROF_COUNT(i, v) do {} while (0)
+#endif
+
 template <int W>
 struct Psi {
     u64 w[W];
@@ -256,6 +282,9 @@ __device__ void rips_sweep(int n, int E, int Ev, const u16* ord, Psi<W>* psi, KE
                 for (int w = 0; w < NVW; ++w) nz |= act[w] && pnz(pxor(x[w], base));
                 if (__ballot(nz)) {
                     // ---- rare path: some triangle's boundary is a non-trivial class ----
+#ifdef TDA_PROFILE
+                    unsigned long long kt0 = clock64();
+#endif
                     const float key = keyfn(r, a, b);
                     for (int guard = 0; guard < 64 * W + 2; ++guard) {
                         WAVE_SYNC();
@@ -307,7 +336,12 @@ __device__ void rips_sweep(int n, int E, int Ev, const u16* ord, Psi<W>* psi, KE
                                 alive[c] &= ~(1ull << ybit);
                                 if (lane == ybit) brank[c] = -1;
                             }
+                        PROF_COUNT(10, 1);
                     }
+#ifdef TDA_PROFILE
+                    PROF_COUNT(4, clock64() - kt0);
+                    PROF_COUNT(11, 1);
+#endif
                 }
             }
             // insert the edge into the graph
@@ -489,6 +523,7 @@ rips_cloud_kernel(const double* __restrict__ src, const int* __restrict__ tau_or
         }
         return;
     }
+    PROF_BEGIN();
     // 1. cloud -> LDS, per-column min-max to [0,1] (range 0 -> 1)
     for (int k = 0; k < dim; ++k) {
         double mn = INFINITY, mx = -INFINITY;
@@ -527,7 +562,9 @@ rips_cloud_kernel(const double* __restrict__ src, const int* __restrict__ tau_or
     for (int off = 32; off > 0; off >>= 1) Ev += __shfl_xor(Ev, off, 64);
     Ev = uni(Ev);
     WAVE_SYNC();
+    PROF_MARK(0);
     bitonic_sort_lds(S, npad);
+    PROF_MARK(1);
     // 3. compact S -> ord in place, chunk by chunk (chunk r0 writes bytes [2 r0, 2 r0 + 128),
     //    all of which belong to entries < r0 + 16 <= already loaded)
     for (int r0 = 0; r0 < E; r0 += 64) {
@@ -538,10 +575,14 @@ rips_cloud_kernel(const double* __restrict__ src, const int* __restrict__ tau_or
         WAVE_SYNC();
     }
     int k0, k1, st;
+    PROF_MARK(2);
     if (P <= 64)
         rips_sweep<1, W>(P, E, Ev, ord, psi, kf, h0, out.h0_cap, h1, out.h1_cap, k0, k1, st);
     else
         rips_sweep<2, W>(P, E, Ev, ord, psi, kf, h0, out.h0_cap, h1, out.h1_cap, k0, k1, st);
+    PROF_MARK(3);
+    PROF_COUNT(8, 1);
+    PROF_COUNT(9, E);
     if (lane == 0) { out.h0_cnt[win] = k0; out.h1_cnt[win] = k1; out.status[win] = st; }
 }
 
