@@ -5,39 +5,39 @@
 // scripts/utils.py:131 (incl. the Takens embedding utils.py:107-116 and the min-max
 // normalisation utils.py:127-130 in front of it).
 //
-// One window per 64-thread workgroup (= one wavefront, so every step is wave-synchronous
-// and needs no s_barrier).  Algorithm (NOT ripser's; designed for a single wave):
+// One window per workgroup of NT = 256 threads (4 waves); everything between the input read
+// and the diagram rows lives in LDS / registers.  The algorithm is NOT ripser's (heap columns
+// do not map to a GPU); it is an edge-parallel formulation of the same persistence pairing:
 //
-//  1. all n(n-1)/2 float32 edge lengths are packed as (sortable key << 16 | a << 8 | b)
-//     and bitonic-sorted in LDS.
-//  2. one sweep over the edges in filtration order keeps, in registers,
-//       * adj[v]   : adjacency bit rows of the graph so far (lane v <-> vertex v),
-//       * comp[v]  : connected-component label (H0 by label propagation = Kruskal),
-//       * for every currently alive H1 class one bit; brank/bkey[bit] live in lane `bit`;
-//     and in LDS psi[edge] = the class of the cycle "edge + tree path" as a bit vector
-//     over alive classes.  For edge e=(a,b) with common-neighbour mask M = adj[a]&adj[b]:
-//       M == 0, different components : H0 death at |e|            (negative edge)
-//       M == 0, same component       : a new H1 class is born     (positive edge)
-//       M != 0                       : e is killed at once by the triangle (a,b,v*),
-//             v* = lowest vertex of M:  psi[e] = psi[a,v*] ^ psi[b,v*]; every other
-//             triangle (a,b,v), v in M, has boundary class psi[e]^psi[a,v]^psi[b,v]; if
-//             that is non-zero the YOUNGEST class in it dies at |e| and is substituted
-//             out of the whole psi table (elder rule).  Such kills happen exactly once
-//             per off-diagonal H1 point, so the table pass is rare.
-//     The multiset of (birth,death) pairs equals that of any persistence algorithm on the
-//     same filtration; tie order inside equal diameters does not change it.
-//  3. rows are written as float64 (float32-exact) pairs: H0 ascending death then the
-//     essential rows; H1 rows are ordered by a second tiny kernel (descending birth).
+//  P0  all n(n-1)/2 float32 edge lengths are packed as (sortable key << 16 | a << 8 | b);
+//  P1  bitonic sort in LDS (whole workgroup);
+//  P2  ord[r] = (a,b) of the r-th edge, rank[a][b] = r (0x7fff for absent edges, d > thresh);
+//  P3  sweep over the filtration in chunks of NT consecutive edges, ONE EDGE PER LANE:
+//      a. common-neighbour mask  M_r = { v : rank[a][v] < r and rank[b][v] < r }  (4 vertices per
+//         64-bit LDS read, borrow-free packed 16-bit compare) -- no sequential adjacency state;
+//      b. edges with M_r = 0 are the only candidates for negative (spanning-forest) edges: a
+//         short sequential union-find over just those decides   merge -> H0 death at |e|
+//                                                               else  -> a new H1 class is born;
+//      c. every other edge is killed at once by its triangle with the lowest apex v*:
+//         psi[e] = psi[a,v*] ^ psi[b,v*], where psi[edge] in LDS is the class of the cycle
+//         "edge + forest path" as a bit vector over the currently alive H1 classes
+//         (dependencies inside the chunk are resolved in a few rounds);
+//      d. each lane scans its other triangles (a,b,v), v in M_r: boundary class
+//         psi[e]^psi[a,v]^psi[b,v].  The earliest non-zero one in the chunk kills the YOUNGEST
+//         class in it (elder rule): that class is substituted out of the whole psi table, the
+//         pair (birth, |e|) is emitted, and the scan resumes.  This happens exactly once per
+//         H1 class that ever dies (tens per window), so the table pass is rare.
+//      The multiset of (birth,death) pairs equals that of any persistence algorithm on the
+//      same filtration; tie order inside equal diameters does not change it.
+//  P4  rows are written as float64 (float32-exact) pairs: H0 ascending death then the essential
+//      rows; H1 rows are ordered by a second tiny kernel (descending birth).
 //
-// LDS per workgroup: 23.8 KB (n = 47, 128 classes) .. 80.2 KB (n = 124 point cloud), see
-// rips_lds_bytes().  No MFMA: this is irregular integer work.
+// LDS per workgroup: 31 KB (n = 47, 128 classes) .. 112 KB (n = 124 point cloud).
+// No MFMA: this is irregular integer work; the roofline that binds it is LDS latency/issue.
 #include "common.h"
 
-#define WAVE_SYNC()                                            \
-    do {                                                       \
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); \
-        __builtin_amdgcn_wave_barrier();                       \
-    } while (0)
+#define NT 256
+#define RANK_NONE 0x7fffu
 
 // ---- optional phase profiling (make PROFILE=1): cycle sums per phase over all windows ----
 #ifdef TDA_PROFILE
@@ -46,10 +46,10 @@ __device__ unsigned long long g_prof[16];
 #define PROF_MARK(i)                                                       \
     do {                                                                   \
         unsigned long long prof_t1 = clock64();                            \
-        if (lane_id() == 0) atomicAdd(&g_prof[i], prof_t1 - prof_t0);      \
+        if (threadIdx.x == 0) atomicAdd(&g_prof[i], prof_t1 - prof_t0);    \
         prof_t0 = prof_t1;                                                 \
     } while (0)
-#define PROF_COUNT(i, v) do { if (lane_id() == 0) atomicAdd(&g_prof[i], (unsigned long long)(v)); } while (0)
+#define PROF_COUNT(i, v) do { if (threadIdx.x == 0) atomicAdd(&g_prof[i], (unsigned long long)(v)); } while (0)
 extern "C" __attribute__((visibility("default"))) int tda_profile_read(unsigned long long* out, int reset)
 {
     if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_prof), sizeof(unsigned long long) * 16) != hipSuccess) return 1;
@@ -66,10 +66,9 @@ extern "C" __attribute__((visibility("default"))) int tda_profile_read(unsigned 
 #endif
 
 template <int W>
-struct Psi {
+struct __attribute__((aligned(8))) Psi {
     u64 w[W];
 };
-
 template <int W>
 __device__ __forceinline__ Psi<W> pxor(Psi<W> a, Psi<W> b)
 {
@@ -94,67 +93,51 @@ __device__ __forceinline__ Psi<W> pzero()
     for (int i = 0; i < W; ++i) r.w[i] = 0;
     return r;
 }
-template <int W>
-__device__ __forceinline__ Psi<W> prl(Psi<W> a, int lane)
-{
-    Psi<W> r;
-#pragma unroll
-    for (int i = 0; i < W; ++i) r.w[i] = rl64(a.w[i], lane);
-    return r;
-}
 
-// "write lane": this clang has no writelane builtin; a compare+select is 3 VALU ops
-__device__ __forceinline__ u64 wl64(u64 val, int lane, u64 old)
-{
-    return (lane_id() == lane) ? val : old;
-}
-
-__device__ __forceinline__ int wave_max_i32(int v)
-{
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        int o = __shfl_xor(v, off, 64);
-        v = o > v ? o : v;
-    }
-    return v;
-}
 __device__ __forceinline__ double wave_min_f64(double v)
 {
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        double o = __shfl_xor(v, off, 64);
-        v = o < v ? o : v;
-    }
+    for (int off = 32; off > 0; off >>= 1) { const double o = __shfl_xor(v, off, 64); v = o < v ? o : v; }
     return v;
 }
 __device__ __forceinline__ double wave_max_f64(double v)
 {
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        double o = __shfl_xor(v, off, 64);
-        v = o > v ? o : v;
-    }
+    for (int off = 32; off > 0; off >>= 1) { const double o = __shfl_xor(v, off, 64); v = o > v ? o : v; }
     return v;
 }
 
 __device__ __forceinline__ int tri2(int v) { return (v * (v - 1)) >> 1; }
+// index of unordered pair {x,y}, x != y
+__device__ __forceinline__ int pair_index(int x, int y) { return x > y ? tri2(x) + y : tri2(y) + x; }
 
-// in-LDS bitonic sort of npad (power of two) u64 keys by one wave
+// flat edge index e = tri2(a)+b (a > b)  ->  a
+__device__ __forceinline__ int edge_row(int e)
+{
+    int a = (int)((1.0f + sqrtf(1.0f + 8.0f * (float)e)) * 0.5f);
+    while (tri2(a) > e) --a;
+    while (tri2(a + 1) <= e) ++a;
+    return a;
+}
+
+// in-LDS bitonic sort of npad (power of two >= 2*NT) u64 keys by the whole workgroup
 __device__ void bitonic_sort_lds(u64* S, int npad)
 {
-    const int lane = lane_id();
+    const int tid = threadIdx.x;
+    const int half = npad >> 1;
     for (int k = 2; k <= npad; k <<= 1) {
         for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int t = lane; t < (npad >> 1); t += 64) {
-                // t-th compare-exchange of this stage: i has bit j clear
-                int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
-                int l = i | j;
-                u64 x = S[i], y = S[l];
-                bool up = (i & k) == 0;
-                bool sw = up ? (x > y) : (x < y);
-                if (sw) { S[i] = y; S[l] = x; }
+#pragma unroll 4
+            for (int t = tid; t < half; t += NT) {
+                const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+                const int l = i | j;
+                const u64 x = S[i], y = S[l];
+                const bool up = (i & k) == 0;
+                const u64 lo = x < y ? x : y, hi = x < y ? y : x;
+                S[i] = up ? lo : hi;
+                S[l] = up ? hi : lo;
             }
-            WAVE_SYNC();
+            __syncthreads();
         }
     }
 }
@@ -165,207 +148,249 @@ struct RipsOut {
     int* status;
 };
 
+struct RipsLayout {
+    int off_ord, off_rank, off_aux, off_misc;   // psi (and the sort array) start at 0
+    int rank_stride;                            // u16 elements per rank row (multiple of 4)
+    int total;
+};
+
+// misc block (byte offsets inside off_misc)
+#define MISC_COMP 0                        // int comp[128]
+#define MISC_BRANK 512                     // int brank[256]
+#define MISC_BKEY (512 + 1024)             // float bkey[256]
+#define MISC_CAND (512 + 2048)             // u64 cand[4]
+#define MISC_WV (512 + 2048 + 32)          // Psi<4> scratch
+#define MISC_MIN (512 + 2048 + 64)         // u32 minkey
+#define MISC_DONE (512 + 2048 + 80)        // u8 done[NT]
+#define MISC_BYTES (512 + 2048 + 80 + NT)
+
 // ---------------------------------------------------------------------------------
-// The sweep.  KEYFN(r, a, b) returns the float32 length of sorted edge r = (a,b).
+// The sweep (phase P3).  KEYFN(r, a, b) returns the float32 length of sorted edge r = (a,b).
+// All control flow is workgroup-uniform; ord/rank/psi/misc live in LDS.
 // ---------------------------------------------------------------------------------
 template <int NVW, int W, class KEYFN>
-__device__ void rips_sweep(int n, int E, int Ev, const u16* ord, Psi<W>* psi, KEYFN keyfn,
-                           double* h0, int h0_cap, double* h1, int h1_cap,
+__device__ void rips_sweep(int n, int E, int Ev, const u16* ord, const u16* rank, int ns, Psi<W>* psi,
+                           unsigned char* misc, KEYFN keyfn, double* h0, int h0_cap, double* h1, int h1_cap,
                            int& out_k0, int& out_k1, int& out_status)
 {
-    const int lane = lane_id();
-    // zero the class table
-    for (int e = lane; e < E; e += 64) psi[e] = pzero<W>();
-    WAVE_SYNC();
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    int* comp = reinterpret_cast<int*>(misc + MISC_COMP);
+    int* brank = reinterpret_cast<int*>(misc + MISC_BRANK);
+    float* bkey = reinterpret_cast<float*>(misc + MISC_BKEY);
+    u64* cand = reinterpret_cast<u64*>(misc + MISC_CAND);
+    Psi<W>* wvs = reinterpret_cast<Psi<W>*>(misc + MISC_WV);
+    u32* minkey = reinterpret_cast<u32*>(misc + MISC_MIN);
+    unsigned char* done = misc + MISC_DONE;
 
-    u64 adj[NVW][NVW];   // adj[set][word]: rows lane+64*set, bits of vertices 64*word..
-    int comp[NVW];
-    int tv[NVW];
-#pragma unroll
-    for (int s = 0; s < NVW; ++s) {
-#pragma unroll
-        for (int w = 0; w < NVW; ++w) adj[s][w] = 0;
-        comp[s] = lane + 64 * s;
-        tv[s] = tri2(lane + 64 * s);
-    }
+    for (int e = tid; e < E; e += NT) psi[e] = pzero<W>();
+    if (tid < 128) comp[tid] = tid;
+    if (tid < 64 * W) { brank[tid] = -1; bkey[tid] = 0.f; }
+    __syncthreads();
+
     u64 alive[W];
-    int brank[W];
-    float bkey[W];
 #pragma unroll
-    for (int c = 0; c < W; ++c) { alive[c] = 0; brank[c] = -1; bkey[c] = 0.f; }
-
+    for (int c = 0; c < W; ++c) alive[c] = 0;
     int k0 = 0, k1 = 0, merges = 0, status = 0;
 
-    for (int r0 = 0; r0 < Ev && !(status & TDA_WIN_CLASS_OVERFLOW); r0 += 64) {
-        const int cnt = (Ev - r0) < 64 ? (Ev - r0) : 64;
-        const u32 ochunk = (r0 + lane < Ev) ? (u32)ord[r0 + lane] : 0u;
-        for (int q = 0; q < cnt; ++q) {
-            const int r = r0 + q;
-            const u32 pk = rl32(ochunk, q);
-            const int a = (int)(pk >> 8), b = (int)(pk & 255u);   // a > b
-            const int ta = tri2(a), tb = tri2(b);
-            const int tab = ta + b;
-            // adjacency rows of a and b
-            u64 ra[NVW], rb[NVW];
-            if (NVW == 1) {
-                ra[0] = rl64(adj[0][0], a);
-                rb[0] = rl64(adj[0][0], b);
-            } else {
+    int clen = NT;
+    for (int r0 = 0; r0 < Ev && !status; r0 += clen) {
+        clen = NT;
+        const int r = r0 + tid;
+        const bool valid = r < Ev;
+        int a = 1, b = 0;
+        if (valid) { const u32 pk = ord[r]; a = (int)(pk >> 8); b = (int)(pk & 255u); }
+        const int tab = tri2(a) + b;
+        // ---- a. common-neighbour mask from the rank rows of a and b ----
+        u64 M[NVW];
 #pragma unroll
-                for (int w = 0; w < NVW; ++w) {
-                    ra[w] = (a < 64) ? rl64(adj[0][w], a) : rl64(adj[NVW - 1][w], a - 64);
-                    rb[w] = (b < 64) ? rl64(adj[0][w], b) : rl64(adj[NVW - 1][w], b - 64);
-                }
+        for (int w = 0; w < NVW; ++w) M[w] = 0;
+        if (valid) {
+            const u64* ra = reinterpret_cast<const u64*>(rank + a * ns);
+            const u64* rb = reinterpret_cast<const u64*>(rank + b * ns);
+            const u64 H = 0x8000800080008000ull;
+            const u64 RR = (u64)r * 0x0001000100010001ull;
+            const int groups = (n + 3) >> 2;
+            for (int g = 0; g < groups; ++g) {
+                const u64 xa = ra[g], xb = rb[g];
+                // per 16-bit field: (x|0x8000) - r never borrows; bit 15 clear  <=>  x < r
+                const u64 t = ~(((xa | H) - RR) | ((xb | H) - RR)) & H;
+                const u64 nib = ((t >> 15) & 1ull) | ((t >> 30) & 2ull) | ((t >> 45) & 4ull) | ((t >> 60) & 8ull);
+                if (NVW == 1) M[0] |= nib << (4 * g);
+                else M[(g >> 4) & (NVW - 1)] |= nib << (4 * (g & 15));
             }
-            u64 mask[NVW];
-            u64 many = 0;
+        }
+        u64 many = 0;
 #pragma unroll
-            for (int w = 0; w < NVW; ++w) { mask[w] = ra[w] & rb[w]; many |= mask[w]; }
-
-            if (many == 0) {
-                const float key = keyfn(r, a, b);
-                int ca, cb;
-                if (NVW == 1) { ca = (int)rl32((u32)comp[0], a); cb = (int)rl32((u32)comp[0], b); }
-                else {
-                    ca = (a < 64) ? (int)rl32((u32)comp[0], a) : (int)rl32((u32)comp[NVW - 1], a - 64);
-                    cb = (b < 64) ? (int)rl32((u32)comp[0], b) : (int)rl32((u32)comp[NVW - 1], b - 64);
-                }
-                if (ca != cb) {
-                    // negative edge: two components merge, H0 class dies at |e|
-#pragma unroll
-                    for (int s = 0; s < NVW; ++s) comp[s] = (comp[s] == cb) ? ca : comp[s];
+        for (int w = 0; w < NVW; ++w) many |= M[w];
+        const bool is_cand = valid && many == 0;
+        // ---- b. candidates: sequential union-find in rank order (workgroup-uniform loop) ----
+        {
+            const u64 bal = __ballot(is_cand);
+            if (lane == 0) cand[wave] = bal;
+        }
+        done[tid] = 0;
+        __syncthreads();
+        for (int wv = 0; wv < NT / 64; ++wv) {
+            u64 cb = cand[wv];
+            while (cb) {
+                const int q = 64 * wv + __builtin_ctzll(cb);
+                cb &= cb - 1;
+                const int rq = r0 + q;
+                const u32 pk = ord[rq];
+                const int qa = (int)(pk >> 8), qb = (int)(pk & 255u);
+                const int ca = comp[qa], cbb = comp[qb];
+                const float key = keyfn(rq, qa, qb);
+                if (ca != cbb) {
+                    __syncthreads();
+                    if (tid < n && comp[tid] == cbb) comp[tid] = ca;
                     ++merges;
                     if (key != 0.0f) {
-                        if (k0 < h0_cap && lane == 0) { h0[2 * k0] = 0.0; h0[2 * k0 + 1] = (double)key; }
+                        if (k0 < h0_cap && tid == 0) { h0[2 * k0] = 0.0; h0[2 * k0 + 1] = (double)key; }
                         ++k0;
                     }
+                    __syncthreads();
                 } else {
-                    // positive edge with no apex yet: a new H1 class
                     int cw = -1, bit = 0;
 #pragma unroll
                     for (int c = W - 1; c >= 0; --c) {
-                        u64 fr = ~alive[c];
+                        const u64 fr = ~alive[c];
                         if (fr) { cw = c; bit = __builtin_ctzll(fr); }
                     }
-                    if (cw < 0) { status |= TDA_WIN_CLASS_OVERFLOW; break; }
-                    Psi<W> nv = pzero<W>();
+                    if (cw < 0) {
+                        // every class bit is in use: close the chunk just before this edge so that the
+                        // kills of the shortened chunk can free bits (capacity = classes alive at once)
+                        if (q == 0) status |= TDA_WIN_CLASS_OVERFLOW;
+                        else clen = q;
+                        break;
+                    }
 #pragma unroll
                     for (int c = 0; c < W; ++c)
-                        if (c == cw) {
-                            alive[c] |= (1ull << bit);
-                            nv.w[c] = (1ull << bit);
-                            if (lane == bit) { brank[c] = r; bkey[c] = key; }
-                        }
-                    if (lane == 0) psi[tab] = nv;
-                }
-            } else {
-                // apparent edge: killed by triangle (a,b,v*), then test the other triangles
-                Psi<W> x[NVW];
-                bool act[NVW];
-#pragma unroll
-                for (int w = 0; w < NVW; ++w) {
-                    const int v = lane + 64 * w;
-                    act[w] = (mask[w] >> lane) & 1ull;
-                    x[w] = pzero<W>();
-                    if (act[w]) {
-                        const int ia = (v < a) ? ta + v : tv[w] + a;
-                        const int ib = (v < b) ? tb + v : tv[w] + b;
-                        x[w] = pxor(psi[ia], psi[ib]);
-                    }
-                }
-                Psi<W> base;
-                if (NVW == 1 || mask[0]) base = prl(x[0], __builtin_ctzll(mask[0]));
-                else base = prl(x[NVW - 1], __builtin_ctzll(mask[NVW - 1]));
-                if (lane == 0) psi[tab] = base;
-                bool nz = false;
-#pragma unroll
-                for (int w = 0; w < NVW; ++w) nz |= act[w] && pnz(pxor(x[w], base));
-                if (__ballot(nz)) {
-                    // ---- rare path: some triangle's boundary is a non-trivial class ----
-#ifdef TDA_PROFILE
-                    unsigned long long kt0 = clock64();
-#endif
-                    const float key = keyfn(r, a, b);
-                    for (int guard = 0; guard < 64 * W + 2; ++guard) {
-                        WAVE_SYNC();
-                        const Psi<W> pe = psi[tab];
-                        Psi<W> wv = pzero<W>();
-                        bool found = false;
-#pragma unroll
-                        for (int w = 0; w < NVW; ++w) {
-                            const int v = lane + 64 * w;
-                            Psi<W> y = pzero<W>();
-                            if (act[w]) {
-                                const int ia = (v < a) ? ta + v : tv[w] + a;
-                                const int ib = (v < b) ? tb + v : tv[w] + b;
-                                y = pxor(pxor(psi[ia], psi[ib]), pe);
-                            }
-                            const u64 bal = __ballot(act[w] && pnz(y));
-                            if (!found && bal) { found = true; wv = prl(y, __builtin_ctzll(bal)); }
-                        }
-                        if (!found) break;
-                        // youngest class of wv (largest birth rank)
-                        int cand = -1;
+                        if (c == cw) alive[c] |= (1ull << bit);
+                    if (tid == 0) {
+                        Psi<W> nv = pzero<W>();
 #pragma unroll
                         for (int c = 0; c < W; ++c)
-                            if ((wv.w[c] >> lane) & 1ull) cand = brank[c] > cand ? brank[c] : cand;
-                        const int ymax = wave_max_i32(cand);
-                        int ycw = 0, ybit = 0;
-                        float ybirth = 0.f;
-#pragma unroll
-                        for (int c = 0; c < W; ++c) {
-                            const u64 bal = __ballot(((wv.w[c] >> lane) & 1ull) && brank[c] == ymax);
-                            if (bal) { ycw = c; ybit = __builtin_ctzll(bal); ybirth = __uint_as_float(rl32(__float_as_uint(bkey[c]), ybit)); }
-                        }
-                        if (key > ybirth) {
-                            if (k1 < h1_cap && lane == 0) { h1[2 * k1] = (double)ybirth; h1[2 * k1 + 1] = (double)key; }
-                            ++k1;
-                        }
-                        // substitute the dead class out of the table
-                        for (int e = lane; e < E; e += 64) {
-                            Psi<W> p = psi[e];
-                            u64 sel = 0;
-#pragma unroll
-                            for (int c = 0; c < W; ++c)
-                                if (c == ycw) sel = (p.w[c] >> ybit) & 1ull;
-                            if (sel) psi[e] = pxor(p, wv);
-                        }
-#pragma unroll
-                        for (int c = 0; c < W; ++c)
-                            if (c == ycw) {
-                                alive[c] &= ~(1ull << ybit);
-                                if (lane == ybit) brank[c] = -1;
-                            }
-                        PROF_COUNT(10, 1);
+                            if (c == cw) nv.w[c] = (1ull << bit);
+                        psi[tri2(qa) + qb] = nv;
+                        brank[64 * cw + bit] = rq;
+                        bkey[64 * cw + bit] = key;
                     }
-#ifdef TDA_PROFILE
-                    PROF_COUNT(4, clock64() - kt0);
-                    PROF_COUNT(11, 1);
-#endif
                 }
             }
-            // insert the edge into the graph
-            if (NVW == 1) {
-                adj[0][0] = wl64(ra[0] | (1ull << b), a, adj[0][0]);
-                adj[0][0] = wl64(rb[0] | (1ull << a), b, adj[0][0]);
-            } else {
-#pragma unroll
-                for (int w = 0; w < NVW; ++w) {
-                    const u64 na = ra[w] | (((b >> 6) == w) ? (1ull << (b & 63)) : 0ull);
-                    const u64 nb = rb[w] | (((a >> 6) == w) ? (1ull << (a & 63)) : 0ull);
-                    if (a < 64) adj[0][w] = wl64(na, a, adj[0][w]);
-                    else adj[NVW - 1][w] = wl64(na, a - 64, adj[NVW - 1][w]);
-                    if (b < 64) adj[0][w] = wl64(nb, b, adj[0][w]);
-                    else adj[NVW - 1][w] = wl64(nb, b - 64, adj[NVW - 1][w]);
-                }
-            }
-            WAVE_SYNC();
+            if (status || clen < NT) break;
         }
+        if (status) break;
+        __syncthreads();
+        // ---- c. apparent edges: psi[e] = psi[a,v*] ^ psi[b,v*] ----
+        int vstar = 0;
+        if (NVW == 1 || M[0]) vstar = __builtin_ctzll(M[0] | (many ? 0ull : 1ull));
+        else vstar = 64 + __builtin_ctzll(M[NVW - 1]);
+        const bool apparent = valid && many != 0 && tid < clen;
+        int d1 = 0, d2 = 0, q1 = 0, q2 = 0;
+        if (apparent) {
+            d1 = pair_index(a, vstar); d2 = pair_index(b, vstar);
+            q1 = (int)rank[a * ns + vstar] - r0; q2 = (int)rank[b * ns + vstar] - r0;   // < tid
+        }
+        bool pending = apparent;
+        if (!apparent) done[tid] = 1;       // candidates (and idle lanes) are settled
+        __syncthreads();
+        Psi<W> base = pzero<W>();
+        while (true) {
+            bool ready = false;
+            if (pending) ready = (q1 < 0 || done[q1]) && (q2 < 0 || done[q2]);
+            __syncthreads();                 // all flag reads of this round precede its flag writes
+            if (pending && ready) {
+                base = pxor(psi[d1], psi[d2]);
+                psi[tab] = base;
+                done[tid] = 1;
+                pending = false;
+            }
+            if (__syncthreads_count(pending) == 0) break;
+        }
+        // ---- d. the other triangles of every apparent edge ----
+        u64 m[NVW];
+#pragma unroll
+        for (int w = 0; w < NVW; ++w) m[w] = apparent ? M[w] : 0ull;
+        if (apparent) {
+            if (NVW == 1 || vstar < 64) m[0] &= ~(1ull << vstar);
+            else m[NVW - 1] &= ~(1ull << (vstar - 64));
+        }
+        bool found = false;
+        int cur_v = 0, ia = 0, ib = 0;
+        for (int guard = 0; guard <= 64 * W; ++guard) {
+            // resume / continue the scan
+            if (found) {
+                base = psi[tab];
+                const Psi<W> y = pxor(pxor(psi[ia], psi[ib]), base);
+                found = pnz(y);
+            }
+            while (!found) {
+                int v;
+                if (NVW == 1) {
+                    if (!m[0]) break;
+                    v = __builtin_ctzll(m[0]); m[0] &= m[0] - 1;
+                } else {
+                    if (m[0]) { v = __builtin_ctzll(m[0]); m[0] &= m[0] - 1; }
+                    else if (m[NVW - 1]) { v = 64 + __builtin_ctzll(m[NVW - 1]); m[NVW - 1] &= m[NVW - 1] - 1; }
+                    else break;
+                }
+                ia = pair_index(a, v); ib = pair_index(b, v);
+                const Psi<W> y = pxor(pxor(psi[ia], psi[ib]), base);
+                if (pnz(y)) { found = true; cur_v = v; }
+            }
+            if (tid == 0) *minkey = 0xffffffffu;
+            __syncthreads();
+            const u32 mykey = ((u32)tid << 8) | (u32)cur_v;
+            if (found) atomicMin(minkey, mykey);
+            __syncthreads();
+            const u32 mk = *minkey;
+            if (mk == 0xffffffffu) break;
+            // ---- kill: the earliest non-trivial triangle of the chunk ----
+            if (found && mykey == mk) *wvs = pxor(pxor(psi[ia], psi[ib]), base);
+            __syncthreads();
+            const Psi<W> wv = *wvs;
+            const int rk = r0 + (int)(mk >> 8);
+            int best = -1, ybit = 0, ycw = 0;
+#pragma unroll
+            for (int c = 0; c < W; ++c) {
+                u64 bits = wv.w[c];
+                while (bits) {
+                    const int i = __builtin_ctzll(bits);
+                    bits &= bits - 1;
+                    const int br = brank[64 * c + i];
+                    if (br > best) { best = br; ybit = i; ycw = c; }
+                }
+            }
+            const float ybirth = bkey[64 * ycw + ybit];
+            const u32 pkk = ord[rk];
+            const float key = keyfn(rk, (int)(pkk >> 8), (int)(pkk & 255u));
+            if (key > ybirth) {
+                if (k1 < h1_cap && tid == 0) { h1[2 * k1] = (double)ybirth; h1[2 * k1 + 1] = (double)key; }
+                ++k1;
+            }
+            __syncthreads();
+            for (int e = tid; e < E; e += NT) {
+                Psi<W> p = psi[e];
+                u64 sel = 0;
+#pragma unroll
+                for (int c = 0; c < W; ++c)
+                    if (c == ycw) sel = (p.w[c] >> ybit) & 1ull;
+                if (sel) psi[e] = pxor(p, wv);
+            }
+#pragma unroll
+            for (int c = 0; c < W; ++c)
+                if (c == ycw) alive[c] &= ~(1ull << ybit);
+            if (tid == 0) brank[64 * ycw + ybit] = -1;
+            __syncthreads();
+            PROF_COUNT(10, 1);
+        }
+        __syncthreads();
     }
     // essential classes
     const int ncomp = n - merges;
     for (int i = 0; i < ncomp; ++i) {
-        if (k0 < h0_cap && lane == 0) { h0[2 * k0] = 0.0; h0[2 * k0 + 1] = (double)INFINITY; }
+        if (k0 < h0_cap && tid == 0) { h0[2 * k0] = 0.0; h0[2 * k0 + 1] = (double)INFINITY; }
         ++k0;
     }
 #pragma unroll
@@ -374,8 +399,7 @@ __device__ void rips_sweep(int n, int E, int Ev, const u16* ord, Psi<W>* psi, KE
         while (al) {
             const int bit = __builtin_ctzll(al);
             al &= al - 1;
-            const float bk = __uint_as_float(rl32(__float_as_uint(bkey[c]), bit));
-            if (k1 < h1_cap && lane == 0) { h1[2 * k1] = (double)bk; h1[2 * k1 + 1] = (double)INFINITY; }
+            if (k1 < h1_cap && tid == 0) { h1[2 * k1] = (double)bkey[64 * c + bit]; h1[2 * k1 + 1] = (double)INFINITY; }
             ++k1;
         }
     }
@@ -383,77 +407,98 @@ __device__ void rips_sweep(int n, int E, int Ev, const u16* ord, Psi<W>* psi, KE
     out_k0 = k0; out_k1 = k1; out_status = status;
 }
 
+// ord / rank / (skey) from the sorted composites; rank rows pre-filled with RANK_NONE
+template <bool WANT_KEYS>
+__device__ void unpack_sorted(const u64* S, int E, int Ev, int n, u16* ord, u16* rank, int ns, u32* skey)
+{
+    const int tid = threadIdx.x;
+    for (int i = tid; i < n * ns; i += NT) rank[i] = (u16)RANK_NONE;
+    __syncthreads();
+    for (int e = tid; e < E; e += NT) {
+        const u64 c = S[e];
+        const u32 pk = (u32)(c & 0xffffu);
+        const int a = (int)(pk >> 8), b = (int)(pk & 255u);
+        ord[e] = (u16)pk;
+        if (WANT_KEYS) skey[e] = (u32)(c >> 16);
+        const u16 rr = (e < Ev) ? (u16)e : (u16)RANK_NONE;
+        rank[a * ns + b] = rr;
+        rank[b * ns + a] = rr;
+    }
+    __syncthreads();
+}
+
 // ---------------------------------------------------------------------------------
-// distance-matrix flavour (EEG): LDS = [S | psi] [ord u16] [skey u32]
+// distance-matrix flavour (EEG): LDS = [S | psi] [ord] [rank] [skey] [misc]
 // ---------------------------------------------------------------------------------
 struct KeyFromLds {
     const u32* skey;
-    __device__ __forceinline__ float operator()(int r, int, int) const
-    {
-        return sortable_f32((u32)uni((int)skey[r]));
-    }
+    __device__ __forceinline__ float operator()(int r, int, int) const { return sortable_f32(skey[r]); }
 };
 
 template <int NVW, int W>
-__global__ void __launch_bounds__(64)
-rips_dm_kernel(const double* __restrict__ dm, int n_win, int n, float thresh, int symmetrise,
-               int off_ord, int off_key, RipsOut out)
+__global__ void __launch_bounds__(NT)
+rips_dm_kernel(const double* __restrict__ dm, int n_win, int n, float thresh, int symmetrise, RipsLayout L,
+               RipsOut out)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int win = blockIdx.x;
     if (win >= n_win) return;
-    const int lane = lane_id();
+    const int tid = threadIdx.x;
     const int E = tri2(n);
-    int npad = 64;
+    int npad = 2 * NT;
     while (npad < E) npad <<= 1;
     u64* S = reinterpret_cast<u64*>(smem);
-    u16* ord = reinterpret_cast<u16*>(smem + off_ord);
-    u32* skey = reinterpret_cast<u32*>(smem + off_key);
     Psi<W>* psi = reinterpret_cast<Psi<W>*>(smem);
+    u16* ord = reinterpret_cast<u16*>(smem + L.off_ord);
+    u16* rank = reinterpret_cast<u16*>(smem + L.off_rank);
+    u32* skey = reinterpret_cast<u32*>(smem + L.off_aux);
+    unsigned char* misc = smem + L.off_misc;
+    int* red = reinterpret_cast<int*>(misc + MISC_MIN);
 
+    PROF_BEGIN();
     const double* D = dm + (size_t)win * n * n;
     const u32 tkey = f32_sortable(thresh);
-    int Ev = 0;
-    // 1. keys: utils.py:137-139 then ripser's float32 cast
-    for (int a = 1; a < n; ++a) {
-        const int base = tri2(a);
-        for (int b = lane; b < a; b += 64) {
-            double v;
-            if (symmetrise) {
-                v = (D[(size_t)a * n + b] + D[(size_t)b * n + a]) / 2.0;
-                if (v < 0.0) v = 0.0;
-            } else {
-                v = D[(size_t)b * n + a];
-            }
-            const u32 sk = f32_sortable((float)v);
-            S[base + b] = ((u64)sk << 16) | (u64)((a << 8) | b);
-            Ev += (sk <= tkey) ? 1 : 0;
+    // P0. keys: utils.py:137-139 then ripser's float32 cast
+    int ev = 0;
+    for (int e = tid; e < E; e += NT) {
+        const int a = edge_row(e), b = e - tri2(a);
+        double v;
+        if (symmetrise) {
+            v = (D[(size_t)a * n + b] + D[(size_t)b * n + a]) / 2.0;
+            if (v < 0.0) v = 0.0;
+        } else {
+            v = D[(size_t)b * n + a];
         }
+        const u32 sk = f32_sortable((float)v);
+        S[e] = ((u64)sk << 16) | (u64)((a << 8) | b);
+        ev += (sk <= tkey) ? 1 : 0;
     }
-    for (int e = E + lane; e < npad; e += 64) S[e] = ~0ull;
-    // wave-sum of Ev
+    for (int e = E + tid; e < npad; e += NT) S[e] = ~0ull;
+    if (tid == 0) *red = 0;
+    __syncthreads();
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) Ev += __shfl_xor(Ev, off, 64);
-    Ev = uni(Ev);
-    WAVE_SYNC();
+    for (int off = 32; off > 0; off >>= 1) ev += __shfl_xor(ev, off, 64);
+    if ((tid & 63) == 0) atomicAdd(red, ev);
+    __syncthreads();
+    const int Ev = *red;
+    PROF_MARK(0);
     bitonic_sort_lds(S, npad);
-    // 2. unpack (ord/skey live outside the S region)
-    for (int e = lane; e < E; e += 64) {
-        const u64 c = S[e];
-        ord[e] = (u16)(c & 0xffffu);
-        skey[e] = (u32)(c >> 16);
-    }
-    WAVE_SYNC();
+    PROF_MARK(1);
+    unpack_sorted<true>(S, E, Ev, n, ord, rank, L.rank_stride, skey);
+    PROF_MARK(2);
     int k0, k1, st;
     KeyFromLds kf{skey};
-    rips_sweep<NVW, W>(n, E, Ev, ord, psi, kf,
+    rips_sweep<NVW, W>(n, E, Ev, ord, rank, L.rank_stride, psi, misc, kf,
                        out.h0 + (size_t)win * out.h0_cap * 2, out.h0_cap,
                        out.h1 + (size_t)win * out.h1_cap * 2, out.h1_cap, k0, k1, st);
-    if (lane == 0) { out.h0_cnt[win] = k0; out.h1_cnt[win] = k1; out.status[win] = st; }
+    PROF_MARK(3);
+    PROF_COUNT(8, 1);
+    PROF_COUNT(9, E);
+    if (tid == 0) { out.h0_cnt[win] = k0; out.h1_cnt[win] = k1; out.status[win] = st; }
 }
 
 // ---------------------------------------------------------------------------------
-// point-cloud flavour (audio): LDS = [S -> ord in place | psi] [pts f64]
+// point-cloud flavour (audio): LDS = [S | psi] [ord] [rank] [pts f64] [misc]
 // mode 0: Takens embedding of a window (utils.py:107-116) + min-max (utils.py:127-130)
 // mode 1: explicit (P, dim) cloud, optional min-max
 // ---------------------------------------------------------------------------------
@@ -479,19 +524,23 @@ struct KeyFromPts {
 };
 
 template <int W>
-__global__ void __launch_bounds__(64)
+__global__ void __launch_bounds__(NT)
 rips_cloud_kernel(const double* __restrict__ src, const int* __restrict__ tau_or_npts, int n_win,
                   int n_t_or_pcap, int dim, int subsample, int mode, int normalise, float thresh,
-                  int off_psi, int off_pts, int p_max, int* __restrict__ n_points, RipsOut out)
+                  RipsLayout L, int p_max, int* __restrict__ n_points, RipsOut out)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int win = blockIdx.x;
     if (win >= n_win) return;
-    const int lane = lane_id();
+    const int tid = threadIdx.x;
     u64* S = reinterpret_cast<u64*>(smem);
-    u16* ord = reinterpret_cast<u16*>(smem);
-    Psi<W>* psi = reinterpret_cast<Psi<W>*>(smem + off_psi);
-    double* pts = reinterpret_cast<double*>(smem + off_pts);
+    Psi<W>* psi = reinterpret_cast<Psi<W>*>(smem);
+    u16* ord = reinterpret_cast<u16*>(smem + L.off_ord);
+    u16* rank = reinterpret_cast<u16*>(smem + L.off_rank);
+    double* pts = reinterpret_cast<double*>(smem + L.off_aux);
+    unsigned char* misc = smem + L.off_misc;
+    int* red = reinterpret_cast<int*>(misc + MISC_MIN);
+    double* mm = reinterpret_cast<double*>(misc + MISC_BRANK);   // min/max scratch (before the sweep)
 
     double* h0 = out.h0 + (size_t)win * out.h0_cap * 2;
     double* h1 = out.h1 + (size_t)win * out.h1_cap * 2;
@@ -508,14 +557,14 @@ rips_cloud_kernel(const double* __restrict__ src, const int* __restrict__ tau_or
         P = tau_or_npts[win];
         base = src + (size_t)win * n_t_or_pcap * dim;
     }
-    if (n_points && lane == 0) n_points[win] = P;
-    if (P > p_max) {
-        if (lane == 0) { out.h0_cnt[win] = 0; out.h1_cnt[win] = 0; out.status[win] = TDA_WIN_TOO_LARGE; }
+    if (n_points && tid == 0) n_points[win] = P;
+    if (P > p_max || (mode == 0 && tau < 1)) {
+        if (tid == 0) { out.h0_cnt[win] = 0; out.h1_cnt[win] = 0; out.status[win] = TDA_WIN_TOO_LARGE; }
         return;
     }
     if (P < 3) {
         // utils.py:125-126: [[0,0]], [[0,0]]
-        if (lane == 0) {
+        if (tid == 0) {
             if (out.h0_cap > 0) { h0[0] = 0.0; h0[1] = 0.0; }
             if (out.h1_cap > 0) { h1[0] = 0.0; h1[1] = 0.0; }
             out.h0_cnt[win] = 1; out.h1_cnt[win] = 1;
@@ -524,66 +573,68 @@ rips_cloud_kernel(const double* __restrict__ src, const int* __restrict__ tau_or
         return;
     }
     PROF_BEGIN();
-    // 1. cloud -> LDS, per-column min-max to [0,1] (range 0 -> 1)
-    for (int k = 0; k < dim; ++k) {
-        double mn = INFINITY, mx = -INFINITY;
-        for (int i = lane; i < P; i += 64) {
-            const double v = (mode == 0) ? base[i * subsample + k * tau] : base[i * dim + k];
-            pts[i * dim + k] = v;
-            mn = v < mn ? v : mn;
-            mx = v > mx ? v : mx;
-        }
-        if (normalise) {
-            mn = wave_min_f64(mn);
-            mx = wave_max_f64(mx);
-            double rg = mx - mn;
-            if (rg == 0.0) rg = 1.0;
-            for (int i = lane; i < P; i += 64) pts[i * dim + k] = (pts[i * dim + k] - mn) / rg;
-        }
+    // cloud -> LDS, per-column min-max to [0,1] (range 0 -> 1); P <= 128: one wave per column pass
+    for (int idx = tid; idx < P * dim; idx += NT) {
+        const int i = idx / dim, k = idx - i * dim;
+        pts[idx] = (mode == 0) ? base[i * subsample + k * tau] : base[idx];
     }
-    WAVE_SYNC();
-    // 2. keys
+    __syncthreads();
+    if (normalise) {
+        if (tid < 64) {
+            for (int k = 0; k < dim; ++k) {
+                double mn = INFINITY, mx = -INFINITY;
+                for (int i = tid; i < P; i += 64) {
+                    const double v = pts[i * dim + k];
+                    mn = v < mn ? v : mn;
+                    mx = v > mx ? v : mx;
+                }
+                mn = wave_min_f64(mn);
+                mx = wave_max_f64(mx);
+                if (tid == 0) { double rg = mx - mn; if (rg == 0.0) rg = 1.0; mm[2 * k] = mn; mm[2 * k + 1] = rg; }
+            }
+        }
+        __syncthreads();
+        for (int idx = tid; idx < P * dim; idx += NT) {
+            const int k = idx % dim;
+            pts[idx] = (pts[idx] - mm[2 * k]) / mm[2 * k + 1];
+        }
+        __syncthreads();
+    }
+    // P0. keys
     const int E = tri2(P);
-    int npad = 64;
+    int npad = 2 * NT;
     while (npad < E) npad <<= 1;
     const u32 tkey = f32_sortable(thresh);
     KeyFromPts kf{pts, dim};
-    int Ev = 0;
-    for (int a = 1; a < P; ++a) {
-        const int tb = tri2(a);
-        for (int b = lane; b < a; b += 64) {
-            const u32 sk = f32_sortable(kf(0, a, b));
-            S[tb + b] = ((u64)sk << 16) | (u64)((a << 8) | b);
-            Ev += (sk <= tkey) ? 1 : 0;
-        }
+    int ev = 0;
+    for (int e = tid; e < E; e += NT) {
+        const int a = edge_row(e), b = e - tri2(a);
+        const u32 sk = f32_sortable(kf(0, a, b));
+        S[e] = ((u64)sk << 16) | (u64)((a << 8) | b);
+        ev += (sk <= tkey) ? 1 : 0;
     }
-    for (int e = E + lane; e < npad; e += 64) S[e] = ~0ull;
+    for (int e = E + tid; e < npad; e += NT) S[e] = ~0ull;
+    if (tid == 0) *red = 0;
+    __syncthreads();
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) Ev += __shfl_xor(Ev, off, 64);
-    Ev = uni(Ev);
-    WAVE_SYNC();
+    for (int off = 32; off > 0; off >>= 1) ev += __shfl_xor(ev, off, 64);
+    if ((tid & 63) == 0) atomicAdd(red, ev);
+    __syncthreads();
+    const int Ev = *red;
     PROF_MARK(0);
     bitonic_sort_lds(S, npad);
     PROF_MARK(1);
-    // 3. compact S -> ord in place, chunk by chunk (chunk r0 writes bytes [2 r0, 2 r0 + 128),
-    //    all of which belong to entries < r0 + 16 <= already loaded)
-    for (int r0 = 0; r0 < E; r0 += 64) {
-        const int e = r0 + lane;
-        const u64 c = (e < E) ? S[e] : 0ull;
-        WAVE_SYNC();
-        if (e < E) ord[e] = (u16)(c & 0xffffu);
-        WAVE_SYNC();
-    }
-    int k0, k1, st;
+    unpack_sorted<false>(S, E, Ev, P, ord, rank, L.rank_stride, nullptr);
     PROF_MARK(2);
+    int k0, k1, st;
     if (P <= 64)
-        rips_sweep<1, W>(P, E, Ev, ord, psi, kf, h0, out.h0_cap, h1, out.h1_cap, k0, k1, st);
+        rips_sweep<1, W>(P, E, Ev, ord, rank, L.rank_stride, psi, misc, kf, h0, out.h0_cap, h1, out.h1_cap, k0, k1, st);
     else
-        rips_sweep<2, W>(P, E, Ev, ord, psi, kf, h0, out.h0_cap, h1, out.h1_cap, k0, k1, st);
+        rips_sweep<2, W>(P, E, Ev, ord, rank, L.rank_stride, psi, misc, kf, h0, out.h0_cap, h1, out.h1_cap, k0, k1, st);
     PROF_MARK(3);
     PROF_COUNT(8, 1);
     PROF_COUNT(9, E);
-    if (lane == 0) { out.h0_cnt[win] = k0; out.h1_cnt[win] = k1; out.status[win] = st; }
+    if (tid == 0) { out.h0_cnt[win] = k0; out.h1_cnt[win] = k1; out.status[win] = st; }
 }
 
 // ---------------------------------------------------------------------------------
@@ -602,7 +653,7 @@ h1_order_kernel(double* __restrict__ h1, int h1_cap, const int* __restrict__ h1_
     if (k < 2) return;
     double* rows = h1 + (size_t)win * h1_cap * 2;
     for (int i = lane; i < 2 * k; i += 64) buf[i] = rows[i];
-    WAVE_SYNC();
+    __syncthreads();
     for (int i = lane; i < k; i += 64) {
         const double bi = buf[2 * i], di = buf[2 * i + 1];
         int rank = 0;
@@ -621,6 +672,28 @@ h1_order_kernel(double* __restrict__ h1, int h1_cap, const int* __restrict__ h1_
 // ---------------------------------------------------------------------------------
 static inline int align16(int x) { return (x + 15) & ~15; }
 
+static RipsLayout make_layout(int n, int W, int aux_bytes)
+{
+    RipsLayout L;
+    const int E = n * (n - 1) / 2;
+    int npad = 2 * NT;
+    while (npad < E) npad <<= 1;
+    const int psi_bytes = E * W * 8;
+    // the sort array may run past psi into ord/rank (written only after the sort); it must
+    // stop before aux (point cloud: read after the sort) and misc
+    L.off_ord = align16(psi_bytes);
+    int ns = (n + 3) & ~3;
+    if ((ns & 7) == 0) ns += 4;                   // odd multiple of 4: spreads rows over LDS banks
+    L.rank_stride = ns;
+    L.off_rank = align16(L.off_ord + E * 2);
+    int after_rank = align16(L.off_rank + n * ns * 2);
+    if (after_rank < npad * 8) after_rank = align16(npad * 8);
+    L.off_aux = after_rank;
+    L.off_misc = align16(L.off_aux + aux_bytes);
+    L.total = align16(L.off_misc + MISC_BYTES);
+    return L;
+}
+
 static tda_status order_h1(tda_ctx* ctx, double* h1, int h1_cap, int* h1_cnt, int n_win, hipStream_t st)
 {
     if (h1_cap < 2) return TDA_OK;
@@ -635,23 +708,17 @@ template <int NVW, int W>
 static tda_status launch_dm_t(tda_ctx* ctx, const double* dm, int n_win, int n, float thresh, int symmetrise,
                               RipsOut out, hipStream_t st)
 {
-    const int E = n * (n - 1) / 2;
-    int npad = 64;
-    while (npad < E) npad <<= 1;
-    const int s_bytes = npad * 8;
-    const int psi_bytes = E * W * 8;
-    const int off_ord = align16(s_bytes > psi_bytes ? s_bytes : psi_bytes);
-    const int off_key = align16(off_ord + E * 2);
-    const int total = align16(off_key + E * 4);
+    const RipsLayout L = make_layout(n, W, n * (n - 1) / 2 * 4);
     auto kern = rips_dm_kernel<NVW, W>;
-    if (total > 48 * 1024)
+    if (L.total > 48 * 1024)
         TDA_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, total));
-    hipLaunchKernelGGL(kern, dim3(n_win), dim3(64), total, st, dm, n_win, n, thresh, symmetrise, off_ord, off_key,
-                       out);
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, L.total));
+    hipLaunchKernelGGL(kern, dim3(n_win), dim3(NT), L.total, st, dm, n_win, n, thresh, symmetrise, L, out);
     TDA_HIP(ctx, hipGetLastError());
     return TDA_OK;
 }
+
+static const int LDS_MAX = 160 * 1024;
 
 tda_status launch_rips_dm(tda_ctx* ctx, const double* dm, int n_win, int n, double thresh, int symmetrise,
                           double* h0, int h0_cap, int* h0_cnt, double* h1, int h1_cap, int* h1_cnt, int* status,
@@ -663,16 +730,15 @@ tda_status launch_rips_dm(tda_ctx* ctx, const double* dm, int n_win, int n, doub
     RipsOut out{h0, h0_cap, h0_cnt, h1, h1_cap, h1_cnt, status};
     const float th = (float)thresh;
     tda_status rc;
-    const int W = ctx->words_dm;
+    int W = ctx->words_dm;
+    // largest class capacity that still fits the 160 KiB LDS
+    while (W > 1 && make_layout(n, W, n * (n - 1) / 2 * 4).total > LDS_MAX) W >>= 1;
     if (n <= 64) {
         if (W == 1) rc = launch_dm_t<1, 1>(ctx, dm, n_win, n, th, symmetrise, out, st);
         else if (W == 2) rc = launch_dm_t<1, 2>(ctx, dm, n_win, n, th, symmetrise, out, st);
         else rc = launch_dm_t<1, 4>(ctx, dm, n_win, n, th, symmetrise, out, st);
     } else {
-        // 128 classes only while [psi | ord | skey] still fits the 160 KiB LDS (n <= 112)
-        const int E = n * (n - 1) / 2;
-        const bool fits2 = (size_t)E * 16 + (size_t)E * 6 + 64 <= 160 * 1024;
-        if (W == 1 || !fits2) rc = launch_dm_t<2, 1>(ctx, dm, n_win, n, th, symmetrise, out, st);
+        if (W == 1) rc = launch_dm_t<2, 1>(ctx, dm, n_win, n, th, symmetrise, out, st);
         else rc = launch_dm_t<2, 2>(ctx, dm, n_win, n, th, symmetrise, out, st);
     }
     if (rc != TDA_OK) return rc;
@@ -684,21 +750,14 @@ static tda_status launch_cloud_t(tda_ctx* ctx, const double* src, const int* aux
                                  int dim, int subsample, int mode, int normalise, float thresh, int p_max,
                                  int* n_points, RipsOut out, hipStream_t st)
 {
-    const int E = p_max * (p_max - 1) / 2;
-    int npad = 64;
-    while (npad < E) npad <<= 1;
-    const int off_psi = align16(E * 2);
-    const int psi_end = off_psi + E * W * 8;
-    const int s_bytes = npad * 8;
-    const int off_pts = align16(psi_end > s_bytes ? psi_end : s_bytes);
-    const int total = align16(off_pts + p_max * dim * 8);
-    if (total > 160 * 1024) TDA_FAIL(ctx, TDA_ERR_UNSUPPORTED, "point cloud too large for LDS");
+    const RipsLayout L = make_layout(p_max, W, p_max * dim * 8);
+    if (L.total > LDS_MAX) TDA_FAIL(ctx, TDA_ERR_UNSUPPORTED, "point cloud too large for LDS");
     auto kern = rips_cloud_kernel<W>;
-    if (total > 48 * 1024)
+    if (L.total > 48 * 1024)
         TDA_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, total));
-    hipLaunchKernelGGL(kern, dim3(n_win), dim3(64), total, st, src, aux, n_win, n_t_or_pcap, dim, subsample, mode,
-                       normalise, thresh, off_psi, off_pts, p_max, n_points, out);
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, L.total));
+    hipLaunchKernelGGL(kern, dim3(n_win), dim3(NT), L.total, st, src, aux, n_win, n_t_or_pcap, dim, subsample, mode,
+                       normalise, thresh, L, p_max, n_points, out);
     TDA_HIP(ctx, hipGetLastError());
     return TDA_OK;
 }
@@ -719,13 +778,15 @@ tda_status launch_rips_cloud(tda_ctx* ctx, const double* src, const int* aux, in
     } else {
         p_max = n_t_or_pcap;
     }
-    if (p_max > TDA_MAX_POINTS) p_max = TDA_MAX_POINTS;   // larger windows are flagged per window
+    if (p_max > TDA_MAX_POINTS) p_max = TDA_MAX_POINTS;   // larger clouds are flagged per window
     if (p_max < 3) p_max = 3;
     if (h0_cap < p_max) TDA_FAIL(ctx, TDA_ERR_INVALID, "h0_cap must be >= max points per cloud");
     RipsOut out{h0, h0_cap, h0_cnt, h1, h1_cap, h1_cnt, status};
     const float th = (float)thresh;
     tda_status rc;
-    if (ctx->words_cloud == 1)
+    int W = ctx->words_cloud;
+    while (W > 1 && make_layout(p_max, W, p_max * dim * 8).total > LDS_MAX) W >>= 1;
+    if (W == 1)
         rc = launch_cloud_t<1>(ctx, src, aux, n_win, n_t_or_pcap, dim, subsample, mode, normalise, th, p_max,
                                n_points, out, st);
     else
