@@ -47,6 +47,38 @@ __device__ __forceinline__ u64 uni64(u64 v)
 }
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
 
+// ---- wave64 reductions on the DPP network (a few VALU cycles per step; __shfl_xor goes through
+// ds_bpermute and costs an LDS round trip per step).  Result is wave-uniform.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_f64(double v)
+{
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    const int lo2 = __builtin_amdgcn_update_dpp(lo, lo, CTRL, ROW_MASK, 0xF, false);
+    const int hi2 = __builtin_amdgcn_update_dpp(hi, hi, CTRL, ROW_MASK, 0xF, false);
+    return __hiloint2double(hi2, lo2);
+}
+__device__ __forceinline__ double uni_f64(double v, int lane)
+{
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+    return __hiloint2double(hi, lo);
+}
+#define TDA_DPP_REDUCE_F64(v, OP)                                                     \
+    do {                                                                              \
+        double o__;                                                                   \
+        o__ = dpp_f64<0xB1, 0xF>(v); v = OP(o__, v);   /* quad_perm [1,0,3,2] */      \
+        o__ = dpp_f64<0x4E, 0xF>(v); v = OP(o__, v);   /* quad_perm [2,3,0,1] */      \
+        o__ = dpp_f64<0x141, 0xF>(v); v = OP(o__, v);  /* row_half_mirror     */      \
+        o__ = dpp_f64<0x140, 0xF>(v); v = OP(o__, v);  /* row_mirror          */      \
+        o__ = dpp_f64<0x142, 0xA>(v); v = OP(o__, v);  /* row_bcast:15        */      \
+        o__ = dpp_f64<0x143, 0xC>(v); v = OP(o__, v);  /* row_bcast:31        */      \
+    } while (0)
+#define TDA_MIN_(a, b) fmin((a), (b))
+#define TDA_MAX_(a, b) fmax((a), (b))
+#define TDA_ADD_(a, b) ((a) + (b))
+__device__ __forceinline__ double wave_min_f64_dpp(double v) { TDA_DPP_REDUCE_F64(v, TDA_MIN_); return uni_f64(v, 63); }
+__device__ __forceinline__ double wave_max_f64_dpp(double v) { TDA_DPP_REDUCE_F64(v, TDA_MAX_); return uni_f64(v, 63); }
+
 // order-preserving float32 <-> uint32 (handles negative values; NaN sorts last)
 __device__ __forceinline__ u32 f32_sortable(float f)
 {

@@ -120,22 +120,42 @@ __device__ __forceinline__ int edge_row(int e)
     return a;
 }
 
-// in-LDS bitonic sort of npad (power of two >= 2*NT) u64 keys by the whole workgroup
+// in-LDS bitonic sort of npad (power of two >= 4*NT... any >= 4) u64 keys by the whole workgroup.
+// Two butterfly stages (j and j/2) are fused per pass: each thread owns the 4 elements
+// {b, b+j/2, b+j, b+3j/2}, so every pass costs one LDS round trip instead of two.
+__device__ __forceinline__ void cex(u64& x, u64& y, bool up)
+{
+    const u64 lo = x < y ? x : y, hi = x < y ? y : x;
+    x = up ? lo : hi;
+    y = up ? hi : lo;
+}
 __device__ void bitonic_sort_lds(u64* S, int npad)
 {
     const int tid = threadIdx.x;
-    const int half = npad >> 1;
     for (int k = 2; k <= npad; k <<= 1) {
-        for (int j = k >> 1; j > 0; j >>= 1) {
+        int j = k >> 1;
+        while (j >= 2) {
+            const int jh = j >> 1;
+#pragma unroll 2
+            for (int t = tid; t < (npad >> 2); t += NT) {
+                const int b = ((t & ~(jh - 1)) << 2) | (t & (jh - 1));
+                const bool up = (b & k) == 0;
+                u64 e0 = S[b], e1 = S[b + jh], e2 = S[b + j], e3 = S[b + j + jh];
+                cex(e0, e2, up); cex(e1, e3, up);
+                cex(e0, e1, up); cex(e2, e3, up);
+                S[b] = e0; S[b + jh] = e1; S[b + j] = e2; S[b + j + jh] = e3;
+            }
+            __syncthreads();
+            j >>= 2;
+        }
+        if (j == 1) {
 #pragma unroll 4
-            for (int t = tid; t < half; t += NT) {
-                const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
-                const int l = i | j;
-                const u64 x = S[i], y = S[l];
+            for (int t = tid; t < (npad >> 1); t += NT) {
+                const int i = t << 1;
                 const bool up = (i & k) == 0;
-                const u64 lo = x < y ? x : y, hi = x < y ? y : x;
-                S[i] = up ? lo : hi;
-                S[l] = up ? hi : lo;
+                u64 x = S[i], y = S[i + 1];
+                cex(x, y, up);
+                S[i] = x; S[i + 1] = y;
             }
             __syncthreads();
         }
@@ -326,18 +346,44 @@ __device__ void rips_sweep(int n, int E, int Ev, const u16* ord, const u16* rank
                 found = pnz(y);
             }
             while (!found) {
-                int v;
-                if (NVW == 1) {
-                    if (!m[0]) break;
-                    v = __builtin_ctzll(m[0]); m[0] &= m[0] - 1;
-                } else {
-                    if (m[0]) { v = __builtin_ctzll(m[0]); m[0] &= m[0] - 1; }
-                    else if (m[NVW - 1]) { v = 64 + __builtin_ctzll(m[NVW - 1]); m[NVW - 1] &= m[NVW - 1] - 1; }
-                    else break;
+                // up to 4 triangles per trip: all 8 LDS reads are issued before the first test
+                int vv[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    int v = -1;
+                    if (NVW == 1) {
+                        if (m[0]) { v = __builtin_ctzll(m[0]); m[0] &= m[0] - 1; }
+                    } else {
+                        if (m[0]) { v = __builtin_ctzll(m[0]); m[0] &= m[0] - 1; }
+                        else if (m[NVW - 1]) { v = 64 + __builtin_ctzll(m[NVW - 1]); m[NVW - 1] &= m[NVW - 1] - 1; }
+                    }
+                    vv[k] = v;
                 }
-                ia = pair_index(a, v); ib = pair_index(b, v);
-                const Psi<W> y = pxor(pxor(psi[ia], psi[ib]), base);
-                if (pnz(y)) { found = true; cur_v = v; }
+                if (vv[0] < 0) break;
+                int ja[4], jb[4];
+                bool nzk[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int v = vv[k] < 0 ? vstar : vv[k];        // padding slot: the (zero) v* triangle
+                    ja[k] = pair_index(a, v); jb[k] = pair_index(b, v);
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) nzk[k] = pnz(pxor(pxor(psi[ja[k]], psi[jb[k]]), base));
+                int hit = -1;
+#pragma unroll
+                for (int k = 3; k >= 0; --k)
+                    if (nzk[k]) hit = k;
+                if (hit >= 0) {
+                    found = true;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        if (k == hit) { cur_v = vv[k]; ia = ja[k]; ib = jb[k]; }
+                        if (k > hit && vv[k] >= 0) {      // not consumed yet: back into the mask
+                            if (NVW == 1 || vv[k] < 64) m[0] |= 1ull << vv[k];
+                            else m[NVW - 1] |= 1ull << (vv[k] - 64);
+                        }
+                    }
+                }
             }
             if (tid == 0) *minkey = 0xffffffffu;
             __syncthreads();

@@ -16,6 +16,24 @@
 // The returned value re-sums the ORIGINAL costs (C_ij, s_i, t_j) of the optimal matching.
 #include "common.h"
 
+#ifdef TDA_PROFILE
+__device__ unsigned long long g_prof_ws[16];
+extern "C" __attribute__((visibility("default"))) int tda_profile_read_ws(unsigned long long* out, int reset)
+{
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_prof_ws), sizeof(unsigned long long) * 16) != hipSuccess) return 1;
+    if (reset) {
+        unsigned long long z[16] = {0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_prof_ws), z, sizeof(z)) != hipSuccess) return 1;
+    }
+    return 0;
+}
+#define WPROF(i, v) do { if (lane_id() == 0) atomicAdd(&g_prof_ws[i], (unsigned long long)(v)); } while (0)
+#define WCLK() clock64()
+#else
+#define WPROF(i, v) do {} while (0)
+#define WCLK() 0ull
+#endif
+
 #define WS_CP 0.7071067811865476   // np.cos(np.pi/4)
 #define WS_SP 0.7071067811865475   // np.sin(np.pi/4)
 
@@ -55,13 +73,14 @@ __global__ void __launch_bounds__(64)
 wasserstein_kernel(const double* __restrict__ dgm_a, const int* __restrict__ cnt_a, int cap_a,
                    const double* __restrict__ dgm_b, const int* __restrict__ cnt_b, int cap_b,
                    const int* __restrict__ idx_a, const int* __restrict__ idx_b, int n_pairs,
-                   int max_rows, int max_cols, int use_matrix,
+                   int max_rows, int max_cols, int mat_entries,
                    double* __restrict__ out, int* __restrict__ status)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int pr = blockIdx.x;
     if (pr >= n_pairs) return;
     const int lane = lane_id();
+    unsigned long long wt0 = WCLK();
     // LDS: row points (b,d,s) | col points (b,d,t) | u[rows] | cost matrix (optional)
     double* rb = reinterpret_cast<double*>(smem);
     double* rd = rb + max_rows;
@@ -92,6 +111,8 @@ wasserstein_kernel(const double* __restrict__ dgm_a, const int* __restrict__ cnt
     // rows = smaller diagram
     const bool a_is_row = Me <= Ne;
     const int R = a_is_row ? Me : Ne, Cn = a_is_row ? Ne : Me;
+    const bool use_matrix = R * Cn <= mat_entries;     // per pair: the cost matrix lives in LDS when it fits
+    const int cw_used = (Cn + 63) >> 6;                // column slots per lane actually in use
     if (R > max_rows || Cn > max_cols || Cn > 64 * CW) {
         if (lane == 0) { out[pr] = __longlong_as_double(0x7ff8000000000000ll); status[pr] = TDA_WIN_NOT_CONVERGED; }
         return;
@@ -139,53 +160,63 @@ wasserstein_kernel(const double* __restrict__ dgm_a, const int* __restrict__ cnt
     }
     for (int i = lane; i < R; i += 64) ru[i] = 0.0;
     __syncthreads();
+    WPROF(0, WCLK() - wt0); wt0 = WCLK();
+    WPROF(4, 1); WPROF(5, R); WPROF(6, Cn);
 
-    // per-lane column state: column j = lane + 64*c
-    double v[CW], minv[CW];
+    // per-lane state, all in registers: column j = lane + 64*c holds v, minv, way, used, prow;
+    // row i = lane + 64*c holds its dual u and the "row is in the alternating tree" flag.
+    // The Dijkstra step therefore touches LDS only for the cost row (one read per column slot).
+    double v[CW], minv[CW], u[CW];
     int prow[CW], way[CW];
-    bool used[CW];
+    bool used[CW], rowin[CW];
 #pragma unroll
-    for (int c = 0; c < CW; ++c) { v[c] = 0.0; prow[c] = -1; way[c] = -1; }
+    for (int c = 0; c < CW; ++c) { v[c] = 0.0; u[c] = 0.0; prow[c] = -1; way[c] = -1; }
 
     const double INF = __longlong_as_double(0x7ff0000000000000ll);
     bool failed = false;
+    int nsteps = 0;
     for (int i = 0; i < R && !failed; ++i) {
 #pragma unroll
-        for (int c = 0; c < CW; ++c) { minv[c] = INF; used[c] = false; }
+        for (int c = 0; c < CW; ++c) { minv[c] = INF; used[c] = false; rowin[c] = (lane + 64 * c) == i; }
         int i0 = i, j0 = -1;            // j0 = -1 is the virtual start column holding row i
         int steps = 0;
         while (true) {
-            const double ui0 = ru[i0];
+            double ui0 = 0.0;
+#pragma unroll
+            for (int c = 0; c < CW; ++c)
+                if (c == (i0 >> 6)) ui0 = uni_f64(u[c], i0 & 63);
             double best = INF;
 #pragma unroll
             for (int c = 0; c < CW; ++c) {
+                if (c >= cw_used) break;
                 const int j = lane + 64 * c;
                 if (j < Cn && !used[c]) {
                     const double g = use_matrix ? G[i0 * Cn + j] : gain(i0, j);
                     const double cur = g - ui0 - v[c];
                     if (cur < minv[c]) { minv[c] = cur; way[c] = j0; }
-                    best = minv[c] < best ? minv[c] : best;
+                    best = fmin(minv[c], best);
                 }
             }
-            const double delta = wave_min_f64_ws(best);
+            const double delta = wave_min_f64_dpp(best);
+            ++nsteps;
             // first column attaining delta
             int j1 = -1;
 #pragma unroll
             for (int c = CW - 1; c >= 0; --c) {
+                if (c >= cw_used) continue;
                 const int j = lane + 64 * c;
                 const u64 bal = __ballot(j < Cn && !used[c] && minv[c] == delta);
                 if (bal) j1 = 64 * c + __builtin_ctzll(bal);
             }
             if (j1 < 0 || !(delta < INF) || ++steps > Cn + 2) { failed = true; break; }
-            // dual update
-            __syncthreads();
+            // dual update: rows in the tree, used / unused columns
 #pragma unroll
             for (int c = 0; c < CW; ++c) {
-                if (used[c]) { ru[prow[c]] += delta; v[c] -= delta; }
+                if (c >= cw_used) break;
+                if (rowin[c]) u[c] += delta;
+                if (used[c]) v[c] -= delta;
                 else minv[c] -= delta;
             }
-            if (lane == 0) ru[i] += delta;      // the virtual column's row
-            __syncthreads();
             // mark j1 used, continue from its row
             const int c1 = j1 >> 6, l1 = j1 & 63;
             int p1 = -1;
@@ -198,6 +229,9 @@ wasserstein_kernel(const double* __restrict__ dgm_a, const int* __restrict__ cnt
             j0 = j1;
             if (p1 < 0) break;          // free column reached: augment
             i0 = p1;
+#pragma unroll
+            for (int c = 0; c < CW; ++c)
+                if (c == (p1 >> 6) && lane == (p1 & 63)) rowin[c] = true;
         }
         if (failed) break;
         // augment along way[] back to the virtual column
@@ -225,6 +259,8 @@ wasserstein_kernel(const double* __restrict__ dgm_a, const int* __restrict__ cnt
         if (lane == 0) { out[pr] = __longlong_as_double(0x7ff8000000000000ll); status[pr] = TDA_WIN_NOT_CONVERGED; }
         return;
     }
+    WPROF(1, WCLK() - wt0); wt0 = WCLK();
+    WPROF(3, nsteps);
     // total = sum over real matches of C_ij + unmatched rows' s + unmatched cols' t
     double part = 0.0;
     __syncthreads();
@@ -248,6 +284,7 @@ wasserstein_kernel(const double* __restrict__ dgm_a, const int* __restrict__ cnt
         if (ru[i] == 0.0) part += rs[i];
     const double total = wave_sum_f64(part);
     if (lane == 0) { out[pr] = total; status[pr] = 0; }
+    WPROF(2, WCLK() - wt0);
 }
 
 // ---------------------------------------------------------------------------------
@@ -262,8 +299,11 @@ tda_status launch_wasserstein(tda_ctx* ctx, const double* dgm_a, const int* cnt_
     if (max_cols > 512) TDA_FAIL(ctx, TDA_ERR_UNSUPPORTED, "diagrams with more than 512 rows are not supported");
     const size_t vec_bytes = (size_t)(4 * max_rows + 3 * max_cols) * 8;
     const size_t mat_bytes = (size_t)max_rows * max_cols * 8;
-    int use_matrix = (vec_bytes + mat_bytes) <= 72 * 1024;
-    const size_t lds = vec_bytes + (use_matrix ? mat_bytes : 0);
+    // LDS budget for the per-pair cost matrix: whole matrix if small, else 48 KB (6144 entries:
+    // enough for 46 x 123 H0 pairs); pairs that do not fit evaluate costs on the fly
+    size_t mat_budget = mat_bytes <= 48 * 1024 ? mat_bytes : 48 * 1024;
+    const int mat_entries = (int)(mat_budget / 8);
+    const size_t lds = vec_bytes + mat_budget;
 #define WS_LAUNCH(CWV)                                                                                         \
     do {                                                                                                       \
         auto kern = wasserstein_kernel<CWV>;                                                                   \
@@ -271,7 +311,7 @@ tda_status launch_wasserstein(tda_ctx* ctx, const double* dgm_a, const int* cnt_
             TDA_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                              \
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));           \
         hipLaunchKernelGGL(kern, dim3(n_pairs), dim3(64), lds, st, dgm_a, cnt_a, cap_a, dgm_b, cnt_b, cap_b,   \
-                           idx_a, idx_b, n_pairs, max_rows, max_cols, use_matrix, out, status);                \
+                           idx_a, idx_b, n_pairs, max_rows, max_cols, mat_entries, out, status);                \
     } while (0)
     if (max_cols <= 128) WS_LAUNCH(2);
     else if (max_cols <= 256) WS_LAUNCH(4);

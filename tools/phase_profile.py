@@ -21,3 +21,18 @@ for band in ["beta", "delta"]:
     n = v[8]
     print(f"audio {band} tau={tau}: windows={int(n)} E/win={v[9]/n:.0f} cycles/win: keygen={v[0]/n:.0f} sort={v[1]/n:.0f} "
           f"compact={v[2]/n:.0f} sweep={v[3]/n:.0f} (of which kill-path={v[4]/n:.0f}; kills/win={v[10]/n:.1f}, kill episodes/win={v[11]/n:.1f})")
+
+# ---- Wasserstein phases on pipeline diagrams ----
+W = synth.eeg_windows(256, seed=3)
+aw = synth.audio_windows(256, "beta", seed=4)
+dist = engine.corr_dist_batch(W, want_corr=False, ctx=ctx)
+e0, ec0, e1, ec1, est = engine.rips_dm_batch(dist, ctx=ctx, raw=True)
+a0, ac0, a1, ac1, npts, ast = engine.takens_rips_batch(aw, 3, ctx=ctx, raw=True)
+for name, (x, cx, y, cy) in {"H0": (e0, ec0, a0, ac0), "H1": (e1, ec1, a1, ac1)}.items():
+    engine.wasserstein_batch(x, cx, y, cy, ctx=ctx)
+    lib.tda_profile_read_ws(buf, 1)
+    engine.wasserstein_batch(x, cx, y, cy, ctx=ctx)
+    lib.tda_profile_read_ws(buf, 1)
+    v = np.array(list(buf), dtype=np.float64); n = v[4]
+    print(f"wasserstein {name}: pairs={int(n)} rows={v[5]/n:.1f} cols={v[6]/n:.1f} cycles/pair: setup={v[0]/n:.0f} "
+          f"solve={v[1]/n:.0f} total={v[2]/n:.0f}; dijkstra steps/pair={v[3]/n:.1f} -> {v[1]/max(v[3],1):.0f} cycles/step")
