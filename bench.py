@@ -153,14 +153,14 @@ def main():
 def cpu_baseline(eeg, aud, seg_off, budget_s):
     """CPU oracle (C restatement of the ripser-class algorithm + persim's assignment), 1 core,
     timed on whole recordings of the SAME batch until ~budget_s seconds are spent."""
-    from tda_eeg_audio_amd import pipeline
+    from oracle import pipeline_ref      # the ONLY use of oracle/ here: the timed CPU port
     done = 0
     t0 = time.perf_counter()
     s = 0
     n_seg = len(seg_off) - 1
     while True:
         a, b = int(seg_off[s % n_seg]), int(seg_off[s % n_seg + 1])
-        pipeline.reference_step_cpu(eeg[a:b], aud[a:b], np.array([0, b - a]))
+        pipeline_ref.reference_step_cpu(eeg[a:b], aud[a:b], np.array([0, b - a]))
         done += b - a
         s += 1
         el = time.perf_counter() - t0

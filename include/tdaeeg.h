@@ -81,6 +81,14 @@ tda_status tda_corr_dist_batch_dev(tda_ctx* ctx, const double* win, int n_win, i
 tda_status tda_corr_dist_batch(tda_ctx* ctx, const double* win, int n_win, int n_ch, int n_t,
                                double* dist, double* corr);
 
+/* correlation_to_distance (nb2:100-122) alone, on stored correlation matrices.
+ * method: 0 "euclidean" (the only one the reference calls, nb2:227,304,312), 1 "abs",
+ *         2 "standard", 3 "sqrt" (nb2:109-116).  corr, dist: (n_win, n, n) float64.          */
+tda_status tda_corr_to_dist_batch_dev(tda_ctx* ctx, const double* corr, int n_win, int n, int method,
+                                      double* dist, void* stream);
+tda_status tda_corr_to_dist_batch(tda_ctx* ctx, const double* corr, int n_win, int n, int method,
+                                  double* dist);
+
 /* ---- Vietoris-Rips H0/H1 from distance matrices -----------------------------
  * replaces compute_eeg_persistence (scripts/utils.py:135-141) ==
  * compute_persistence_diagram (scripts/tda_eeg_classification_v2.py:143-176):

@@ -72,6 +72,15 @@ tda_status tda_corr_dist_batch_dev(tda_ctx* ctx, const double* win, int n_win, i
     return launch_corr_dist(ctx, win, n_win, n_ch, n_t, dist, corr, (hipStream_t)stream);
 }
 
+tda_status tda_corr_to_dist_batch_dev(tda_ctx* ctx, const double* corr, int n_win, int n, int method, double* dist,
+                                      void* stream)
+{
+    CHECK_CTX(ctx); CHECK_NONNEG(ctx, n_win);
+    if (n_win) { CHECK_PTR(ctx, corr); CHECK_PTR(ctx, dist); }
+    if (n < 1) TDA_FAIL(ctx, TDA_ERR_INVALID, "n must be >= 1");
+    return launch_corr_to_dist(ctx, corr, n_win, n, method, dist, (hipStream_t)stream);
+}
+
 tda_status tda_rips_dm_batch_dev(tda_ctx* ctx, const double* dm, int n_win, int n, double thresh, int symmetrise,
                                  double* h0, int h0_cap, int* h0_cnt, double* h1, int h1_cap, int* h1_cnt,
                                  int* status, void* stream)
@@ -207,6 +216,22 @@ tda_status tda_corr_dist_batch(tda_ctx* ctx, const double* win, int n_win, int n
     if (corr) s.add((void**)&d_corr, nullptr, corr, nw * n_ch * n_ch * 8);
     RET_IF(s.upload());
     RET_IF(tda_corr_dist_batch_dev(ctx, d_win, n_win, n_ch, n_t, d_dist, d_corr, nullptr));
+    return s.download();
+}
+
+tda_status tda_corr_to_dist_batch(tda_ctx* ctx, const double* corr, int n_win, int n, int method, double* dist)
+{
+    CHECK_CTX(ctx); CHECK_NONNEG(ctx, n_win);
+    if (n_win == 0) return TDA_OK;
+    CHECK_PTR(ctx, corr); CHECK_PTR(ctx, dist);
+    if (n < 1) TDA_FAIL(ctx, TDA_ERR_INVALID, "n must be >= 1");
+    TDA_HIP(ctx, hipSetDevice(ctx->device));
+    Stage s(ctx);
+    double *d_c, *d_d;
+    s.add((void**)&d_c, corr, nullptr, (size_t)n_win * n * n * 8);
+    s.add((void**)&d_d, nullptr, dist, (size_t)n_win * n * n * 8);
+    RET_IF(s.upload());
+    RET_IF(tda_corr_to_dist_batch_dev(ctx, d_c, n_win, n, method, d_d, nullptr));
     return s.download();
 }
 

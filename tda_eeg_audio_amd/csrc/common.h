@@ -93,6 +93,7 @@ __device__ __forceinline__ float sortable_f32(u32 s)
 
 // launch-side entry points implemented in the .hip files
 tda_status launch_corr_dist(tda_ctx*, const double*, int, int, int, double*, double*, hipStream_t);
+tda_status launch_corr_to_dist(tda_ctx*, const double*, int, int, int, double*, hipStream_t);
 tda_status launch_rips_dm(tda_ctx*, const double*, int, int, double, int, double*, int, int*, double*, int, int*,
                           int*, hipStream_t);
 tda_status launch_rips_cloud(tda_ctx*, const double* win_or_pc, const int* tau_or_npts, int n_win, int n_t_or_pcap,

@@ -117,6 +117,42 @@ corr_dist_kernel(const double* __restrict__ win, int n_win, int n_ch, int n_t,
     }
 }
 
+// correlation_to_distance (nb2:100-122) on stored correlation matrices: all four methods.
+// method: 0 "euclidean" sqrt(2(1-r)) | 1 "abs" 1-|r| | 2 "standard" 1-r | 3 "sqrt" sqrt(1-r^2)
+__global__ void __launch_bounds__(256)
+corr_to_dist_kernel(const double* __restrict__ corr, long long total, int n, int method, double* __restrict__ dist)
+{
+    const long long nn = (long long)n * n;
+    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+        const long long e = idx % nn;
+        const int i = (int)(e / n), j = (int)(e - (long long)i * n);
+        double r = corr[idx];
+        if (r > 1.0) r = 1.0;              // np.clip(corr, -1, 1), nb2:105 (NaN stays NaN)
+        if (r < -1.0) r = -1.0;
+        double d;
+        if (method == 0) d = sqrt(2.0 * (1.0 - r));
+        else if (method == 1) d = 1.0 - fabs(r);
+        else if (method == 2) d = 1.0 - r;
+        else d = sqrt(1.0 - r * r);
+        if (d < 0.0) d = 0.0;              // np.maximum(d, 0), nb2:119 (NaN propagates like numpy)
+        if (i == j) d = 0.0;               // nb2:120
+        dist[idx] = d;
+    }
+}
+
+tda_status launch_corr_to_dist(tda_ctx* ctx, const double* corr, int n_win, int n, int method, double* dist,
+                               hipStream_t st)
+{
+    if (n_win == 0) return TDA_OK;
+    if (method < 0 || method > 3) TDA_FAIL(ctx, TDA_ERR_INVALID, "Unknown method");
+    const long long total = (long long)n_win * n * n;
+    long long blocks = (total + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(corr_to_dist_kernel, dim3((unsigned)blocks), dim3(256), 0, st, corr, total, n, method, dist);
+    TDA_HIP(ctx, hipGetLastError());
+    return TDA_OK;
+}
+
 tda_status launch_corr_dist(tda_ctx* ctx, const double* win, int n_win, int n_ch, int n_t, double* dist,
                             double* corr, hipStream_t st)
 {

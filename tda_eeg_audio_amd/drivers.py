@@ -1,0 +1,189 @@
+"""
+drivers.py -- batched counterparts of the reference's per-recording drivers, on the
+reference's on-disk formats.
+
+  select_windows_even / select_windows_md5   window selection, reproduced exactly (host side):
+        np.linspace(0, n-1, 15, dtype=int)          scripts/tda_eeg_audio_comparison.py:77-80,
+                                                    scripts/matched_vs_mismatched.py:52-55,77-80
+        default_rng(md5(f"{dir}-{band}-{42}")[:8]).choice(n, size, replace=False)
+                                                    scripts/tda_eeg_classification_v2.py:394-398
+  process_file_features   scripts/tda_eeg_classification_v2.py:338-442  (220 features / recording)
+  get_eeg_diagrams        scripts/matched_vs_mismatched.py:66-85
+  get_audio_diagrams_from_windows / compute_cross_wasserstein   mvm:43-63, 87-95
+  process_recording_arrays  scripts/tda_eeg_audio_comparison.py:63-122 given the band-passed audio
+                            windows (the .mat loading / envelope / filtering in front, cmp:53-65, is
+                            host-side preparation outside this engine)
+"""
+import hashlib
+from pathlib import Path
+
+import numpy as np
+
+from . import engine
+from .utils import FEATURE_KEYS, FREQ_BANDS, MAX_EDGE_LENGTH, TAKENS_DIM, TAKENS_SUBSAMPLE
+
+MAX_WINDOWS = 15            # cmp:39, mvm:32
+BANDS = list(FREQ_BANDS)    # v2:63 order: delta, theta, alpha, beta, gamma
+
+
+def select_windows_even(n_win, max_windows=MAX_WINDOWS):
+    if n_win > max_windows:
+        return np.linspace(0, n_win - 1, max_windows, dtype=int)
+    return np.arange(n_win)
+
+
+def select_windows_md5(dirname, band, n_windows, max_n, random_state=42):
+    max_n = min(int(max_n), n_windows)
+    seed = int(hashlib.md5(f"{dirname}-{band}-{random_state}".encode()).hexdigest()[:8], 16)
+    return np.random.default_rng(seed).choice(n_windows, size=max_n, replace=False)
+
+
+def feature_names(bands=BANDS):
+    """Column order of features/feature_names.txt (v2:429-436)."""
+    names = []
+    for band in bands:
+        for f in FEATURE_KEYS:
+            names += [f"{band}_h0_{f}_mean", f"{band}_h0_{f}_std", f"{band}_h1_{f}_mean", f"{band}_h1_{f}_std"]
+    return names
+
+
+def features_from_distances(dist_list, thresh=MAX_EDGE_LENGTH):
+    """dist_list: list of (k_i, n, n) arrays, one per (recording, band) group, windows already
+    selected.  One Rips launch + two feature launches + one aggregation launch for all groups.
+    Returns (len(dist_list), 44) float64."""
+    sizes = np.array([len(d) for d in dist_list])
+    allw = np.concatenate([np.asarray(d, dtype=np.float64) for d in dist_list if len(d)], axis=0)
+    h0, c0, h1, c1, st = engine.rips_dm_batch(allw, thresh=thresh, raw=True)
+    if (st & 2).any():
+        raise RuntimeError("H1 class capacity exceeded")
+    f0 = engine.features_batch(h0, c0)
+    f1 = engine.features_batch(h1, c1)
+    seg = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int32)
+    return engine.aggregate_batch(f0, f1, seg)
+
+
+def process_file_features(file_dir, freq_bands=BANDS, max_dim=1, max_edge_length=MAX_EDGE_LENGTH,
+                          max_windows_per_band=None, window_sampling="random", random_state=42):
+    """v2:338-442 -- returns (features dict in reference key order, metadata)."""
+    file_dir = Path(file_dir)
+    metadata = {"n_windows": {}, "n_windows_used": {}, "validation_issues": [],
+                "window_sampling": window_sampling, "max_windows_per_band": max_windows_per_band}
+    groups, bands_present = [], []
+    for band in freq_bands:
+        dist_file = file_dir / f"{band}_distances.npy"
+        if not dist_file.exists():
+            metadata["n_windows"][band] = 0
+            continue
+        try:
+            dms = np.load(dist_file)
+        except Exception as e:
+            metadata["validation_issues"].append(f"{band}: error de carga - {e}")
+            continue
+        n_windows = dms.shape[0]
+        metadata["n_windows"][band] = n_windows
+        if n_windows == 0:
+            continue
+        if max_windows_per_band is None:
+            use = np.arange(n_windows)
+        else:
+            max_n = max_windows_per_band.get(band, n_windows) if isinstance(max_windows_per_band, dict) \
+                else int(max_windows_per_band)
+            max_n = min(max_n, n_windows)
+            use = select_windows_md5(file_dir.name, band, n_windows, max_n, random_state) \
+                if window_sampling == "random" else np.arange(max_n)
+        metadata["n_windows_used"][band] = len(use)
+        groups.append(dms[use]); bands_present.append(band)
+    file_features = {}
+    if groups:
+        agg = features_from_distances(groups, max_edge_length)
+        for g, band in enumerate(bands_present):
+            k = 0
+            for f in FEATURE_KEYS:
+                for tag in ("h0", "h1"):
+                    for stat in ("mean", "std"):
+                        file_features[f"{band}_{tag}_{f}_{stat}"] = agg[g, k]
+                        k += 1
+    metadata["n_windows_total"] = int(sum(metadata["n_windows"].values()))
+    metadata["n_windows_used_total"] = int(sum(metadata["n_windows_used"].values()))
+    return file_features, metadata
+
+
+def get_eeg_diagrams(graph_dir, bands=BANDS):
+    """mvm:66-85 -- {band: [[H0, H1] per selected window]} from <band>_distances.npy."""
+    graph_dir = Path(graph_dir)
+    if not graph_dir.exists():
+        return None
+    result = {}
+    for bname in bands:
+        dist_file = graph_dir / f"{bname}_distances.npy"
+        if not dist_file.exists():
+            continue
+        dms = np.load(str(dist_file))
+        if dms.shape[0] == 0:
+            continue
+        idx = select_windows_even(dms.shape[0])
+        h0, h1, st = engine.rips_dm_batch(dms[idx])
+        result[bname] = [[a, b] for a, b in zip(h0, h1)]
+    return result
+
+
+def get_audio_diagrams_from_windows(audio_wins):
+    """mvm:50-62 for one band: selected windows, tau from the first one, Takens + Rips; windows
+    whose cloud has < 3 points are skipped (mvm:60)."""
+    n_win = len(audio_wins)
+    if n_win == 0:
+        return []
+    idx = select_windows_even(n_win)
+    sel = np.asarray(audio_wins, dtype=np.float64)[idx]
+    tau = int(engine.tau_batch(sel[:1], max_lag=sel.shape[1] // 2)[0])
+    h0, h1, npts, st = engine.takens_rips_batch(sel, tau, TAKENS_DIM, TAKENS_SUBSAMPLE)
+    return [[a, b] for a, b, p in zip(h0, h1, npts) if p >= 3]
+
+
+def compute_cross_wasserstein(eeg_dgms_band, audio_dgms_band):
+    """mvm:87-95 -- nanmean of W(H1, H1) over windows paired by index."""
+    n = min(len(eeg_dgms_band), len(audio_dgms_band))
+    if n == 0:
+        return np.nan
+    ra, ca = engine.pack_diagrams([d[1] for d in eeg_dgms_band[:n]])
+    rb, cb = engine.pack_diagrams([d[1] for d in audio_dgms_band[:n]])
+    w, st = engine.wasserstein_batch(ra, ca, rb, cb, want_status=True)
+    w = np.where(st == 0, w, np.nan)
+    return float(engine.segment_nanmean(w, np.array([0, n], np.int32))[0])
+
+
+def process_recording_arrays(audio_band_windows, eeg_dists_by_band):
+    """cmp:63-122 for one recording.  audio_band_windows: {band: (n_a, 250) band-passed audio
+    windows}; eeg_dists_by_band: {band: (n_e, 47, 47)}.  Returns {band: {...}} with the keys of
+    the reference's per-band result (wasserstein_h0/h1, n_windows, tau) plus the per-window H1
+    feature time series used by its Spearman step (cmp:104-115)."""
+    out = {}
+    for bname in BANDS:
+        if bname not in audio_band_windows or bname not in eeg_dists_by_band:
+            continue
+        aw = np.asarray(audio_band_windows[bname], dtype=np.float64)
+        ed = np.asarray(eeg_dists_by_band[bname], dtype=np.float64)
+        n_win = min(len(aw), ed.shape[0])
+        if n_win == 0:
+            continue
+        idx = select_windows_even(n_win)
+        tau = int(engine.tau_batch(aw[idx[:1]], max_lag=aw.shape[1] // 2)[0])          # cmp:83
+        a0, ac0, a1, ac1, npts, ast = engine.takens_rips_batch(aw[idx], tau, TAKENS_DIM, TAKENS_SUBSAMPLE, raw=True)
+        keep = npts >= 3                                                               # cmp:90-91
+        if not keep.any():
+            continue
+        e0, ec0, e1, ec1, est = engine.rips_dm_batch(ed[idx], raw=True)
+        k = np.nonzero(keep)[0].astype(np.int32)
+        w0, s0 = engine.wasserstein_batch(e0, ec0, a0, ac0, k, k, want_status=True)
+        w1, s1 = engine.wasserstein_batch(e1, ec1, a1, ac1, k, k, want_status=True)
+        w0 = np.where(s0 == 0, w0, np.nan); w1 = np.where(s1 == 0, w1, np.nan)
+        seg = np.array([0, len(k)], np.int32)
+        fa = engine.features_batch(a1[k], ac1[k])
+        fe = engine.features_batch(e1[k], ec1[k])
+        out[bname] = {
+            "wasserstein_h0": float(engine.segment_nanmean(w0, seg)[0]),
+            "wasserstein_h1": float(engine.segment_nanmean(w1, seg)[0]),
+            "n_windows": int(len(idx)), "tau": tau,
+            "audio_h1_features": fa, "eeg_h1_features": fe,
+        }
+    return out

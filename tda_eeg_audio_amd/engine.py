@@ -36,6 +36,20 @@ def corr_dist_batch(windows, want_corr=True, ctx=None):
     return (corr, dist) if want_corr else dist
 
 
+DIST_METHODS = {"euclidean": 0, "abs": 1, "standard": 2, "sqrt": 3}     # nb2:107-116
+
+
+def corr_to_dist_batch(corr, method="euclidean", ctx=None):
+    if method not in DIST_METHODS:
+        raise ValueError(f"Unknown method: {method}")                      # nb2:117
+    ctx = ctx or get_ctx()
+    c = f64(corr)
+    n_win, n, _ = c.shape
+    dist = np.empty_like(c)
+    ctx.check(ctx.lib.tda_corr_to_dist_batch(ctx.h, ptr(c), n_win, n, DIST_METHODS[method], ptr(dist)))
+    return dist
+
+
 def rips_dm_batch(dms, thresh=MAX_EDGE_LENGTH, symmetrise=True, h1_cap=DEFAULT_H1_CAP, ctx=None, raw=False):
     ctx = ctx or get_ctx()
     d = f64(dms)

@@ -93,35 +93,3 @@ def run_step(eeg_win, audio_win, ws, ctx=None, max_lag=125, timers=None):
 
 
 STAGES = ["corr_dist", "rips_eeg", "tau", "rips_audio", "wasserstein_h0", "wasserstein_h1", "features", "aggregate"]
-
-
-def reference_step_cpu(eeg_win, audio_win, seg_off, max_lag=125):
-    """The same unit on the CPU ORACLE -- test/benchmark infrastructure only (imports oracle/)."""
-    from oracle import port
-    n_win = eeg_win.shape[0]
-    seg_off = np.asarray(seg_off)
-    res = np.empty((len(seg_off) - 1, RESULT_COLS))
-    for s in range(len(seg_off) - 1):
-        a, b = seg_off[s], seg_off[s + 1]
-        tau = port.compute_tau(audio_win[a], max_lag)
-        w0, w1, f0, f1 = [], [], [], []
-        for w in range(a, b):
-            _, d = port.corr_dist(eeg_win[w])
-            e = port.rips_dm(d)
-            (au, P) = port.audio_persistence(audio_win[w], tau)
-            w0.append(port.wasserstein(_clean(e[0]), _clean(au[0])))
-            w1.append(port.wasserstein(_clean(e[1]), _clean(au[1])))
-            f0.append(port.features(e[0])); f1.append(port.features(e[1]))
-            port.features(au[1])
-        f0 = np.array(f0); f1 = np.array(f1)
-        res[s, 0] = np.nanmean(w0); res[s, 1] = np.nanmean(w1); res[s, 2] = tau; res[s, 3] = b - a
-        for f in range(11):
-            res[s, 4 + 4 * f: 8 + 4 * f] = [f0[:, f].mean(), f0[:, f].std(), f1[:, f].mean(), f1[:, f].std()]
-    return res
-
-
-def _clean(d):
-    d = np.asarray(d).reshape(-1, 2)
-    m = np.isfinite(d).all(axis=1)
-    d = d[m]
-    return d if len(d) else np.zeros((1, 2))

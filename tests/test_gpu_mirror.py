@@ -1,0 +1,99 @@
+"""GPU tests of the reference-named mirrors (tda_eeg_audio_amd.utils / graphs / drivers): same
+call shapes as scripts/utils.py and nb2, results checked against the oracle and the golden vectors."""
+import numpy as np
+import pytest
+
+from oracle import brute, port
+from tda_eeg_audio_amd import drivers, graphs, synth, utils
+
+pytestmark = pytest.mark.gpu
+
+
+def _same(a, b):
+    return np.array_equal(brute.sort_rows(a), brute.sort_rows(b))
+
+
+def test_graphs_functions(ctx, golden, tmp_path):
+    W = golden["cd_windows"]
+    c = graphs.compute_correlation_matrix(W[1])
+    d = graphs.correlation_to_distance(c, method="euclidean")
+    assert np.abs(c - golden["cd_corr"][1]).max() < 1e-12
+    assert np.array_equal(d.astype(np.float32), golden["cd_dist"][1].astype(np.float32))
+    r = golden["cd_corr"][0]
+    assert np.allclose(graphs.correlation_to_distance(r, "abs"), np.where(np.eye(47, dtype=bool), 0, 1 - np.abs(r)), atol=1e-15)
+    assert np.allclose(graphs.correlation_to_distance(r, "standard"), np.where(np.eye(47, dtype=bool), 0, 1 - r), atol=1e-15)
+    assert np.allclose(graphs.correlation_to_distance(r, "sqrt"),
+                       np.where(np.eye(47, dtype=bool), 0, np.sqrt(np.maximum(1 - r ** 2, 0))), atol=1e-12)
+    with pytest.raises(ValueError):
+        graphs.correlation_to_distance(r, "nope")
+    # on-disk format round trip (preprocessed/<rec>/<band>.npy -> graphs/<rec>/<band>_*.npy)
+    rec = tmp_path / "preprocessed" / "bb01_ut01"
+    rec.mkdir(parents=True)
+    wins = synth.eeg_windows(7, seed=3)
+    np.save(rec / "alpha.npy", wins)
+    meta, failed = graphs.batch_process_graphs(tmp_path / "preprocessed", tmp_path / "graphs", ["alpha", "beta"])
+    assert failed == [] and meta[0]["bands"]["alpha"]["n_windows"] == 7 and "beta" not in meta[0]["bands"]
+    dist = np.load(tmp_path / "graphs" / "bb01_ut01" / "alpha_distances.npy")
+    corr = np.load(tmp_path / "graphs" / "bb01_ut01" / "alpha_correlations.npy")
+    oc, od = port.corr_dist_batch(wins)
+    assert dist.shape == (7, 47, 47) and np.array_equal(dist, od) and np.array_equal(corr, oc)
+
+
+def test_utils_single_call_mirrors(ctx, golden):
+    D = golden["ep_in"]
+    keep = D.copy()
+    dg = utils.compute_eeg_persistence(D)
+    assert np.array_equal(D, keep) and len(dg) == 2 and dg[0].dtype == np.float64
+    o = port.rips_f32(golden["ep_dm"].astype(np.float32))
+    assert _same(dg[0], o[0]) and _same(dg[1], o[1])
+    with pytest.raises(ValueError):
+        utils.compute_eeg_persistence(np.zeros((3, 4)))
+    s = golden["tau_signals"][3]
+    tau = utils.compute_tau(s, max_lag=125)
+    assert tau == golden["tau_values"][3]
+    pc = utils.takens_embedding(s, utils.TAKENS_DIM, tau, utils.TAKENS_SUBSAMPLE)
+    a = utils.compute_audio_persistence(pc)
+    o = port.rips_f32(golden["pd_beta"].astype(np.float32))
+    assert _same(a[0], o[0]) and _same(a[1], o[1])
+    small = utils.compute_audio_persistence(pc[:2])
+    assert np.array_equal(small[0], [[0, 0]]) and np.array_equal(small[1], [[0, 0]])
+    f = utils.extract_features(golden["ef_in_mixed"])
+    assert list(f) == utils.FEATURE_KEYS and isinstance(f["n_features"], int)
+    assert np.allclose([f[k] for k in utils.FEATURE_KEYS], golden["ef_out_mixed"], rtol=1e-12)
+    w = utils.safe_wasserstein(dg[1], a[1])
+    assert abs(w - brute.safe_wasserstein_oracle(dg[1], a[1])) < 1e-6
+    assert utils.safe_wasserstein(np.zeros((0, 2)), np.array([[0.25, 1.0]])) == \
+        pytest.approx(brute.safe_wasserstein_oracle(np.zeros((0, 2)), np.array([[0.25, 1.0]])), abs=1e-12)
+    assert utils.safe_wasserstein(np.array([1.0, 2.0]), np.array([[0.25, 1.0]])) == \
+        pytest.approx(0.75 / np.sqrt(2), abs=1e-12)            # 1-D input -> [[0,0]] (utils.py:183-184)
+
+
+def test_drivers_process_file_features_and_cross_wasserstein(ctx, tmp_path):
+    rec = tmp_path / "graphs" / "slow" / "bb01_ut01"
+    rec.mkdir(parents=True)
+    dists = {}
+    for bi, band in enumerate(["delta", "gamma"]):
+        W = synth.eeg_windows(50, seed=10 + bi)
+        dists[band] = port.corr_dist_batch(W)[1]
+        np.save(rec / f"{band}_distances.npy", dists[band])
+    feats, meta = drivers.process_file_features(rec, ["delta", "theta", "gamma"], max_windows_per_band=39)
+    assert meta["n_windows"] == {"delta": 50, "theta": 0, "gamma": 50} and meta["n_windows_used"]["delta"] == 39
+    keys = list(feats)
+    assert keys[:4] == ["delta_h0_n_features_mean", "delta_h0_n_features_std", "delta_h1_n_features_mean",
+                        "delta_h1_n_features_std"] and len(keys) == 88
+    use = drivers.select_windows_md5("bb01_ut01", "gamma", 50, 39)
+    f1 = np.array([port.features(port.rips_dm(dists["gamma"][i])[1]) for i in use])
+    assert feats["gamma_h1_total_persistence_mean"] == pytest.approx(f1[:, 9].mean(), rel=1e-12)
+    assert feats["gamma_h1_total_persistence_std"] == pytest.approx(f1[:, 9].std(), rel=1e-12)
+    # matched-vs-mismatched style cross Wasserstein (mvm:87-95)
+    eeg = drivers.get_eeg_diagrams(rec, ["delta"])
+    assert len(eeg["delta"]) == 15
+    aud = drivers.get_audio_diagrams_from_windows(synth.audio_windows(40, "delta", seed=2))
+    w = drivers.compute_cross_wasserstein(eeg["delta"], aud)
+    ref = np.nanmean([brute.safe_wasserstein_oracle(e[1], a[1]) for e, a in zip(eeg["delta"], aud)])
+    assert abs(w - ref) < 1e-6
+    assert np.isnan(drivers.compute_cross_wasserstein([], aud))
+    # comparison driver on arrays (cmp:63-122)
+    out = drivers.process_recording_arrays({"delta": synth.audio_windows(40, "delta", seed=2)}, {"delta": dists["delta"]})
+    assert out["delta"]["n_windows"] == 15 and out["delta"]["tau"] >= 1
+    assert np.isfinite(out["delta"]["wasserstein_h0"]) and out["delta"]["eeg_h1_features"].shape == (15, 11)
