@@ -79,6 +79,15 @@ __device__ __forceinline__ double uni_f64(double v, int lane)
 __device__ __forceinline__ double wave_min_f64_dpp(double v) { TDA_DPP_REDUCE_F64(v, TDA_MIN_); return uni_f64(v, 63); }
 __device__ __forceinline__ double wave_max_f64_dpp(double v) { TDA_DPP_REDUCE_F64(v, TDA_MAX_); return uni_f64(v, 63); }
 
+__device__ __forceinline__ int wave_max_i32_dpp(int v)
+{
+#define TDA_DPP_I32_(CTRL, RM) { const int o__ = __builtin_amdgcn_update_dpp(v, v, CTRL, RM, 0xF, false); v = o__ > v ? o__ : v; }
+    TDA_DPP_I32_(0xB1, 0xF) TDA_DPP_I32_(0x4E, 0xF) TDA_DPP_I32_(0x141, 0xF) TDA_DPP_I32_(0x140, 0xF)
+    TDA_DPP_I32_(0x142, 0xA) TDA_DPP_I32_(0x143, 0xC)
+#undef TDA_DPP_I32_
+    return __builtin_amdgcn_readlane(v, 63);
+}
+
 // order-preserving float32 <-> uint32 (handles negative values; NaN sorts last)
 __device__ __forceinline__ u32 f32_sortable(float f)
 {

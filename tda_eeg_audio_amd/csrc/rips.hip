@@ -36,7 +36,7 @@
 // No MFMA: this is irregular integer work; the roofline that binds it is LDS latency/issue.
 #include "common.h"
 
-#define NT 256
+#define NT_MAX 512            // largest workgroup (point-cloud flavour); distance-matrix flavour uses 256
 #define RANK_NONE 0x7fffu
 
 // ---- optional phase profiling (make PROFILE=1): cycle sums per phase over all windows ----
@@ -129,6 +129,7 @@ __device__ __forceinline__ void cex(u64& x, u64& y, bool up)
     x = up ? lo : hi;
     y = up ? hi : lo;
 }
+template <int NT>
 __device__ void bitonic_sort_lds(u64* S, int npad)
 {
     const int tid = threadIdx.x;
@@ -162,6 +163,42 @@ __device__ void bitonic_sort_lds(u64* S, int npad)
     }
 }
 
+// Scan the remaining triangles (a,b,v), v in one 32-bit mask word (vertices vbase..vbase+31), four
+// per trip (all eight LDS reads are issued before the first test).  Returns true at the first
+// non-trivial boundary class psi[a,v]^psi[b,v]^base and leaves the word positioned just after it.
+template <int W>
+__device__ __forceinline__ bool scan_word(u32& mw, const int vbase, const Psi<W>* psi, const Psi<W> base, int a, int b,
+                                          int ta, int tb, int& cur_v, int& ia, int& ib)
+{
+    while (mw) {
+        u32 mm = mw;
+        const int v0 = vbase + __builtin_ctz(mm); mm &= mm - 1u;
+        const bool ok1 = mm != 0u; const int v1 = ok1 ? vbase + __builtin_ctz(mm) : v0; mm &= mm - 1u;
+        const bool ok2 = mm != 0u; const int v2 = ok2 ? vbase + __builtin_ctz(mm) : v0; mm &= mm - 1u;
+        const bool ok3 = mm != 0u; const int v3 = ok3 ? vbase + __builtin_ctz(mm) : v0; mm &= mm - 1u;
+#define TDA_IDX_(v, ja, jb)                                               \
+        const int t##ja = (int)(__umul24((u32)(v), (u32)((v) - 1)) >> 1); \
+        const int ja = (v) < a ? ta + (v) : t##ja + a;                    \
+        const int jb = (v) < b ? tb + (v) : t##ja + b;
+        TDA_IDX_(v0, ja0, jb0) TDA_IDX_(v1, ja1, jb1) TDA_IDX_(v2, ja2, jb2) TDA_IDX_(v3, ja3, jb3)
+#undef TDA_IDX_
+        const Psi<W> p0 = psi[ja0], q0 = psi[jb0], p1 = psi[ja1], q1 = psi[jb1];
+        const Psi<W> p2 = psi[ja2], q2 = psi[jb2], p3 = psi[ja3], q3 = psi[jb3];
+        const bool n0 = pnz(pxor(pxor(p0, q0), base));
+        const bool n1 = ok1 && pnz(pxor(pxor(p1, q1), base));
+        const bool n2 = ok2 && pnz(pxor(pxor(p2, q2), base));
+        const bool n3 = ok3 && pnz(pxor(pxor(p3, q3), base));
+        if (!(n0 || n1 || n2 || n3)) { mw = mm; continue; }
+        if (n0) { cur_v = v0; ia = ja0; ib = jb0; }
+        else if (n1) { cur_v = v1; ia = ja1; ib = jb1; }
+        else if (n2) { cur_v = v2; ia = ja2; ib = jb2; }
+        else { cur_v = v3; ia = ja3; ib = jb3; }
+        mw &= ~((2u << (cur_v - vbase)) - 1u);      // everything up to the hit is consumed
+        return true;
+    }
+    return false;
+}
+
 struct RipsOut {
     double* h0; int h0_cap; int* h0_cnt;
     double* h1; int h1_cap; int* h1_cnt;
@@ -178,17 +215,18 @@ struct RipsLayout {
 #define MISC_COMP 0                        // int comp[128]
 #define MISC_BRANK 512                     // int brank[256]
 #define MISC_BKEY (512 + 1024)             // float bkey[256]
-#define MISC_CAND (512 + 2048)             // u64 cand[4]
-#define MISC_WV (512 + 2048 + 32)          // Psi<4> scratch
-#define MISC_MIN (512 + 2048 + 64)         // u32 minkey
-#define MISC_DONE (512 + 2048 + 80)        // u8 done[NT]
-#define MISC_BYTES (512 + 2048 + 80 + NT)
+#define MISC_CAND (512 + 2048)             // u64 cand[8]
+#define MISC_WV (512 + 2048 + 64)          // Psi<4> scratch
+#define MISC_MIN (512 + 2048 + 96)         // u32 minkey
+#define MISC_DONE (512 + 2048 + 112)       // u8 done[NT_MAX]
+#define MISC_CKEY (512 + 2048 + 112 + NT_MAX)   // float ckey[NT_MAX]: lengths of this chunk's candidate edges
+#define MISC_BYTES (512 + 2048 + 112 + NT_MAX + 4 * NT_MAX)
 
 // ---------------------------------------------------------------------------------
 // The sweep (phase P3).  KEYFN(r, a, b) returns the float32 length of sorted edge r = (a,b).
 // All control flow is workgroup-uniform; ord/rank/psi/misc live in LDS.
 // ---------------------------------------------------------------------------------
-template <int NVW, int W, class KEYFN>
+template <int NT, int NVW, int W, class KEYFN>
 __device__ void rips_sweep(int n, int E, int Ev, const u16* ord, const u16* rank, int ns, Psi<W>* psi,
                            unsigned char* misc, KEYFN keyfn, double* h0, int h0_cap, double* h1, int h1_cap,
                            int& out_k0, int& out_k1, int& out_status)
@@ -202,6 +240,7 @@ __device__ void rips_sweep(int n, int E, int Ev, const u16* ord, const u16* rank
     Psi<W>* wvs = reinterpret_cast<Psi<W>*>(misc + MISC_WV);
     u32* minkey = reinterpret_cast<u32*>(misc + MISC_MIN);
     unsigned char* done = misc + MISC_DONE;
+    float* ckey = reinterpret_cast<float*>(misc + MISC_CKEY);
 
     for (int e = tid; e < E; e += NT) psi[e] = pzero<W>();
     if (tid < 128) comp[tid] = tid;
@@ -214,8 +253,10 @@ __device__ void rips_sweep(int n, int E, int Ev, const u16* ord, const u16* rank
     int k0 = 0, k1 = 0, merges = 0, status = 0;
 
     int clen = NT;
+    PROF_BEGIN();
     for (int r0 = 0; r0 < Ev && !status; r0 += clen) {
         clen = NT;
+        PROF_MARK(15);
         const int r = r0 + tid;
         const bool valid = r < Ev;
         int a = 1, b = 0;
@@ -231,6 +272,7 @@ __device__ void rips_sweep(int n, int E, int Ev, const u16* ord, const u16* rank
             const u64 H = 0x8000800080008000ull;
             const u64 RR = (u64)r * 0x0001000100010001ull;
             const int groups = (n + 3) >> 2;
+#pragma unroll 4
             for (int g = 0; g < groups; ++g) {
                 const u64 xa = ra[g], xb = rb[g];
                 // per 16-bit field: (x|0x8000) - r never borrows; bit 15 clear  <=>  x < r
@@ -244,11 +286,13 @@ __device__ void rips_sweep(int n, int E, int Ev, const u16* ord, const u16* rank
 #pragma unroll
         for (int w = 0; w < NVW; ++w) many |= M[w];
         const bool is_cand = valid && many == 0;
+        PROF_MARK(4);
         // ---- b. candidates: sequential union-find in rank order (workgroup-uniform loop) ----
         {
             const u64 bal = __ballot(is_cand);
             if (lane == 0) cand[wave] = bal;
         }
+        if (is_cand) ckey[tid] = keyfn(r, a, b);     // every candidate needs its length (H0 death / H1 birth)
         done[tid] = 0;
         __syncthreads();
         for (int wv = 0; wv < NT / 64; ++wv) {
@@ -260,7 +304,7 @@ __device__ void rips_sweep(int n, int E, int Ev, const u16* ord, const u16* rank
                 const u32 pk = ord[rq];
                 const int qa = (int)(pk >> 8), qb = (int)(pk & 255u);
                 const int ca = comp[qa], cbb = comp[qb];
-                const float key = keyfn(rq, qa, qb);
+                const float key = ckey[q];
                 if (ca != cbb) {
                     __syncthreads();
                     if (tid < n && comp[tid] == cbb) comp[tid] = ca;
@@ -302,6 +346,7 @@ __device__ void rips_sweep(int n, int E, int Ev, const u16* ord, const u16* rank
         }
         if (status) break;
         __syncthreads();
+        PROF_MARK(5);
         // ---- c. apparent edges: psi[e] = psi[a,v*] ^ psi[b,v*] ----
         int vstar = 0;
         if (NVW == 1 || M[0]) vstar = __builtin_ctzll(M[0] | (many ? 0ull : 1ull));
@@ -328,14 +373,21 @@ __device__ void rips_sweep(int n, int E, int Ev, const u16* ord, const u16* rank
             }
             if (__syncthreads_count(pending) == 0) break;
         }
+        PROF_MARK(6);
         // ---- d. the other triangles of every apparent edge ----
-        u64 m[NVW];
+        u32 m0, m1, m2 = 0u, m3 = 0u;
+        {
+            u64 mm[NVW];
 #pragma unroll
-        for (int w = 0; w < NVW; ++w) m[w] = apparent ? M[w] : 0ull;
-        if (apparent) {
-            if (NVW == 1 || vstar < 64) m[0] &= ~(1ull << vstar);
-            else m[NVW - 1] &= ~(1ull << (vstar - 64));
+            for (int w = 0; w < NVW; ++w) mm[w] = apparent ? M[w] : 0ull;
+            if (apparent) {
+                if (NVW == 1 || vstar < 64) mm[0] &= ~(1ull << vstar);
+                else mm[NVW - 1] &= ~(1ull << (vstar - 64));
+            }
+            m0 = (u32)mm[0]; m1 = (u32)(mm[0] >> 32);
+            if (NVW == 2) { m2 = (u32)mm[NVW - 1]; m3 = (u32)(mm[NVW - 1] >> 32); }
         }
+        const int ta_ = tri2(a), tb_ = tri2(b);
         bool found = false;
         int cur_v = 0, ia = 0, ib = 0;
         for (int guard = 0; guard <= 64 * W; ++guard) {
@@ -345,45 +397,11 @@ __device__ void rips_sweep(int n, int E, int Ev, const u16* ord, const u16* rank
                 const Psi<W> y = pxor(pxor(psi[ia], psi[ib]), base);
                 found = pnz(y);
             }
-            while (!found) {
-                // up to 4 triangles per trip: all 8 LDS reads are issued before the first test
-                int vv[4];
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    int v = -1;
-                    if (NVW == 1) {
-                        if (m[0]) { v = __builtin_ctzll(m[0]); m[0] &= m[0] - 1; }
-                    } else {
-                        if (m[0]) { v = __builtin_ctzll(m[0]); m[0] &= m[0] - 1; }
-                        else if (m[NVW - 1]) { v = 64 + __builtin_ctzll(m[NVW - 1]); m[NVW - 1] &= m[NVW - 1] - 1; }
-                    }
-                    vv[k] = v;
-                }
-                if (vv[0] < 0) break;
-                int ja[4], jb[4];
-                bool nzk[4];
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const int v = vv[k] < 0 ? vstar : vv[k];        // padding slot: the (zero) v* triangle
-                    ja[k] = pair_index(a, v); jb[k] = pair_index(b, v);
-                }
-#pragma unroll
-                for (int k = 0; k < 4; ++k) nzk[k] = pnz(pxor(pxor(psi[ja[k]], psi[jb[k]]), base));
-                int hit = -1;
-#pragma unroll
-                for (int k = 3; k >= 0; --k)
-                    if (nzk[k]) hit = k;
-                if (hit >= 0) {
-                    found = true;
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        if (k == hit) { cur_v = vv[k]; ia = ja[k]; ib = jb[k]; }
-                        if (k > hit && vv[k] >= 0) {      // not consumed yet: back into the mask
-                            if (NVW == 1 || vv[k] < 64) m[0] |= 1ull << vv[k];
-                            else m[NVW - 1] |= 1ull << (vv[k] - 64);
-                        }
-                    }
-                }
+            if (!found) found = scan_word<W>(m0, 0, psi, base, a, b, ta_, tb_, cur_v, ia, ib);
+            if (!found) found = scan_word<W>(m1, 32, psi, base, a, b, ta_, tb_, cur_v, ia, ib);
+            if (NVW == 2) {
+                if (!found) found = scan_word<W>(m2, 64, psi, base, a, b, ta_, tb_, cur_v, ia, ib);
+                if (!found) found = scan_word<W>(m3, 96, psi, base, a, b, ta_, tb_, cur_v, ia, ib);
             }
             if (tid == 0) *minkey = 0xffffffffu;
             __syncthreads();
@@ -397,16 +415,17 @@ __device__ void rips_sweep(int n, int E, int Ev, const u16* ord, const u16* rank
             __syncthreads();
             const Psi<W> wv = *wvs;
             const int rk = r0 + (int)(mk >> 8);
-            int best = -1, ybit = 0, ycw = 0;
+            // youngest class of wv: lane i looks at bit i of every word (each wave redundantly)
+            int candv = -1;
 #pragma unroll
-            for (int c = 0; c < W; ++c) {
-                u64 bits = wv.w[c];
-                while (bits) {
-                    const int i = __builtin_ctzll(bits);
-                    bits &= bits - 1;
-                    const int br = brank[64 * c + i];
-                    if (br > best) { best = br; ybit = i; ycw = c; }
-                }
+            for (int c = 0; c < W; ++c)
+                if ((wv.w[c] >> lane) & 1ull) { const int br = brank[64 * c + lane]; candv = br > candv ? br : candv; }
+            const int best = wave_max_i32_dpp(candv);
+            int ybit = 0, ycw = 0;
+#pragma unroll
+            for (int c = W - 1; c >= 0; --c) {
+                const u64 bal = __ballot(((wv.w[c] >> lane) & 1ull) && brank[64 * c + lane] == best);
+                if (bal) { ycw = c; ybit = __builtin_ctzll(bal); }
             }
             const float ybirth = bkey[64 * ycw + ybit];
             const u32 pkk = ord[rk];
@@ -416,6 +435,7 @@ __device__ void rips_sweep(int n, int E, int Ev, const u16* ord, const u16* rank
                 ++k1;
             }
             __syncthreads();
+#pragma unroll 4
             for (int e = tid; e < E; e += NT) {
                 Psi<W> p = psi[e];
                 u64 sel = 0;
@@ -432,6 +452,7 @@ __device__ void rips_sweep(int n, int E, int Ev, const u16* ord, const u16* rank
             PROF_COUNT(10, 1);
         }
         __syncthreads();
+        PROF_MARK(7);
     }
     // essential classes
     const int ncomp = n - merges;
@@ -454,7 +475,7 @@ __device__ void rips_sweep(int n, int E, int Ev, const u16* ord, const u16* rank
 }
 
 // ord / rank / (skey) from the sorted composites; rank rows pre-filled with RANK_NONE
-template <bool WANT_KEYS>
+template <int NT, bool WANT_KEYS>
 __device__ void unpack_sorted(const u64* S, int E, int Ev, int n, u16* ord, u16* rank, int ns, u32* skey)
 {
     const int tid = threadIdx.x;
@@ -481,7 +502,7 @@ struct KeyFromLds {
     __device__ __forceinline__ float operator()(int r, int, int) const { return sortable_f32(skey[r]); }
 };
 
-template <int NVW, int W>
+template <int NT, int NVW, int W>
 __global__ void __launch_bounds__(NT)
 rips_dm_kernel(const double* __restrict__ dm, int n_win, int n, float thresh, int symmetrise, RipsLayout L,
                RipsOut out)
@@ -528,13 +549,13 @@ rips_dm_kernel(const double* __restrict__ dm, int n_win, int n, float thresh, in
     __syncthreads();
     const int Ev = *red;
     PROF_MARK(0);
-    bitonic_sort_lds(S, npad);
+    bitonic_sort_lds<NT>(S, npad);
     PROF_MARK(1);
-    unpack_sorted<true>(S, E, Ev, n, ord, rank, L.rank_stride, skey);
+    unpack_sorted<NT, true>(S, E, Ev, n, ord, rank, L.rank_stride, skey);
     PROF_MARK(2);
     int k0, k1, st;
     KeyFromLds kf{skey};
-    rips_sweep<NVW, W>(n, E, Ev, ord, rank, L.rank_stride, psi, misc, kf,
+    rips_sweep<NT, NVW, W>(n, E, Ev, ord, rank, L.rank_stride, psi, misc, kf,
                        out.h0 + (size_t)win * out.h0_cap * 2, out.h0_cap,
                        out.h1 + (size_t)win * out.h1_cap * 2, out.h1_cap, k0, k1, st);
     PROF_MARK(3);
@@ -569,7 +590,7 @@ struct KeyFromPts {
     }
 };
 
-template <int W>
+template <int NT, int W>
 __global__ void __launch_bounds__(NT)
 rips_cloud_kernel(const double* __restrict__ src, const int* __restrict__ tau_or_npts, int n_win,
                   int n_t_or_pcap, int dim, int subsample, int mode, int normalise, float thresh,
@@ -668,15 +689,15 @@ rips_cloud_kernel(const double* __restrict__ src, const int* __restrict__ tau_or
     __syncthreads();
     const int Ev = *red;
     PROF_MARK(0);
-    bitonic_sort_lds(S, npad);
+    bitonic_sort_lds<NT>(S, npad);
     PROF_MARK(1);
-    unpack_sorted<false>(S, E, Ev, P, ord, rank, L.rank_stride, nullptr);
+    unpack_sorted<NT, false>(S, E, Ev, P, ord, rank, L.rank_stride, nullptr);
     PROF_MARK(2);
     int k0, k1, st;
     if (P <= 64)
-        rips_sweep<1, W>(P, E, Ev, ord, rank, L.rank_stride, psi, misc, kf, h0, out.h0_cap, h1, out.h1_cap, k0, k1, st);
+        rips_sweep<NT, 1, W>(P, E, Ev, ord, rank, L.rank_stride, psi, misc, kf, h0, out.h0_cap, h1, out.h1_cap, k0, k1, st);
     else
-        rips_sweep<2, W>(P, E, Ev, ord, rank, L.rank_stride, psi, misc, kf, h0, out.h0_cap, h1, out.h1_cap, k0, k1, st);
+        rips_sweep<NT, 2, W>(P, E, Ev, ord, rank, L.rank_stride, psi, misc, kf, h0, out.h0_cap, h1, out.h1_cap, k0, k1, st);
     PROF_MARK(3);
     PROF_COUNT(8, 1);
     PROF_COUNT(9, E);
@@ -718,7 +739,7 @@ h1_order_kernel(double* __restrict__ h1, int h1_cap, const int* __restrict__ h1_
 // ---------------------------------------------------------------------------------
 static inline int align16(int x) { return (x + 15) & ~15; }
 
-static RipsLayout make_layout(int n, int W, int aux_bytes)
+static RipsLayout make_layout(int n, int W, int aux_bytes, int NT)
 {
     RipsLayout L;
     const int E = n * (n - 1) / 2;
@@ -754,8 +775,9 @@ template <int NVW, int W>
 static tda_status launch_dm_t(tda_ctx* ctx, const double* dm, int n_win, int n, float thresh, int symmetrise,
                               RipsOut out, hipStream_t st)
 {
-    const RipsLayout L = make_layout(n, W, n * (n - 1) / 2 * 4);
-    auto kern = rips_dm_kernel<NVW, W>;
+    const int NT = 256;
+    const RipsLayout L = make_layout(n, W, n * (n - 1) / 2 * 4, NT);
+    auto kern = rips_dm_kernel<256, NVW, W>;
     if (L.total > 48 * 1024)
         TDA_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, L.total));
@@ -778,7 +800,7 @@ tda_status launch_rips_dm(tda_ctx* ctx, const double* dm, int n_win, int n, doub
     tda_status rc;
     int W = ctx->words_dm;
     // largest class capacity that still fits the 160 KiB LDS
-    while (W > 1 && make_layout(n, W, n * (n - 1) / 2 * 4).total > LDS_MAX) W >>= 1;
+    while (W > 1 && make_layout(n, W, n * (n - 1) / 2 * 4, 256).total > LDS_MAX) W >>= 1;
     if (n <= 64) {
         if (W == 1) rc = launch_dm_t<1, 1>(ctx, dm, n_win, n, th, symmetrise, out, st);
         else if (W == 2) rc = launch_dm_t<1, 2>(ctx, dm, n_win, n, th, symmetrise, out, st);
@@ -796,9 +818,10 @@ static tda_status launch_cloud_t(tda_ctx* ctx, const double* src, const int* aux
                                  int dim, int subsample, int mode, int normalise, float thresh, int p_max,
                                  int* n_points, RipsOut out, hipStream_t st)
 {
-    const RipsLayout L = make_layout(p_max, W, p_max * dim * 8);
+    const int NT = 512;
+    const RipsLayout L = make_layout(p_max, W, p_max * dim * 8, NT);
     if (L.total > LDS_MAX) TDA_FAIL(ctx, TDA_ERR_UNSUPPORTED, "point cloud too large for LDS");
-    auto kern = rips_cloud_kernel<W>;
+    auto kern = rips_cloud_kernel<512, W>;
     if (L.total > 48 * 1024)
         TDA_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, L.total));
@@ -831,7 +854,7 @@ tda_status launch_rips_cloud(tda_ctx* ctx, const double* src, const int* aux, in
     const float th = (float)thresh;
     tda_status rc;
     int W = ctx->words_cloud;
-    while (W > 1 && make_layout(p_max, W, p_max * dim * 8).total > LDS_MAX) W >>= 1;
+    while (W > 1 && make_layout(p_max, W, p_max * dim * 8, 512).total > LDS_MAX) W >>= 1;
     if (W == 1)
         rc = launch_cloud_t<1>(ctx, src, aux, n_win, n_t_or_pcap, dim, subsample, mode, normalise, th, p_max,
                                n_points, out, st);

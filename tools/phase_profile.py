@@ -10,6 +10,13 @@ from tda_eeg_audio_amd import engine, synth
 ctx = _lib.get_ctx(0)
 lib = ctx.lib
 buf = (C.c_ulonglong * 16)()
+W_ = synth.eeg_windows(256, seed=3)
+dist_ = engine.corr_dist_batch(W_, want_corr=False, ctx=ctx)
+engine.rips_dm_batch(dist_, ctx=ctx); lib.tda_profile_read(buf, 1)
+engine.rips_dm_batch(dist_, ctx=ctx); lib.tda_profile_read(buf, 1)
+v = np.array(list(buf), dtype=np.float64); n = v[8]
+print(f"eeg: windows={int(n)} E/win={v[9]/n:.0f} cycles/win: keygen={v[0]/n:.0f} sort={v[1]/n:.0f} unpack={v[2]/n:.0f} "
+      f"sweep={v[3]/n:.0f} [mask={v[4]/n:.0f} candidates={v[5]/n:.0f} deps={v[6]/n:.0f} scan+kills={v[7]/n:.0f}] kills/win={v[10]/n:.1f}")
 for band in ["beta", "delta"]:
     wins = synth.audio_windows(256, band, seed=1)
     tau = engine.tau_batch(wins[:1], 125, ctx=ctx)[0]
@@ -20,7 +27,7 @@ for band in ["beta", "delta"]:
     v = np.array(list(buf), dtype=np.float64)
     n = v[8]
     print(f"audio {band} tau={tau}: windows={int(n)} E/win={v[9]/n:.0f} cycles/win: keygen={v[0]/n:.0f} sort={v[1]/n:.0f} "
-          f"compact={v[2]/n:.0f} sweep={v[3]/n:.0f} (of which kill-path={v[4]/n:.0f}; kills/win={v[10]/n:.1f}, kill episodes/win={v[11]/n:.1f})")
+          f"unpack={v[2]/n:.0f} sweep={v[3]/n:.0f} [mask={v[4]/n:.0f} candidates={v[5]/n:.0f} deps={v[6]/n:.0f} scan+kills={v[7]/n:.0f}] kills/win={v[10]/n:.1f}")
 
 # ---- Wasserstein phases on pipeline diagrams ----
 W = synth.eeg_windows(256, seed=3)
