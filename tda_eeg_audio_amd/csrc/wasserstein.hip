@@ -89,7 +89,8 @@ wasserstein_kernel(const double* __restrict__ dgm_a, const int* __restrict__ cnt
     double* cb = ru + max_rows;
     double* cd = cb + max_cols;
     double* ct = cd + max_cols;
-    double* G = ct + max_cols;          // max_rows x max_cols when use_matrix
+    int* owner = reinterpret_cast<int*>(ct + max_cols);                 // max_cols ints (padded to 8 B)
+    double* G = ct + max_cols + ((max_cols + 1) >> 1);                  // mat_entries doubles when the pair fits
 
     const int ia = idx_a ? idx_a[pr] : pr;
     const int ib = idx_b ? idx_b[pr] : pr;
@@ -175,7 +176,43 @@ wasserstein_kernel(const double* __restrict__ dgm_a, const int* __restrict__ cnt
     const double INF = __longlong_as_double(0x7ff0000000000000ll);
     bool failed = false;
     int nsteps = 0;
+    // ---- row-reduction start: u_i = min_j g_ij, v = 0 is dual feasible; every row whose arg-min
+    // column is not claimed by a lower row is assigned at once (tight pair), the rest augment ----
+    bool rowdone[CW];
+    {
+        int myarg[CW];
+        for (int j = lane; j < Cn; j += 64) owner[j] = 0x7fffffff;
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < CW; ++c) {
+            const int r = lane + 64 * c;
+            myarg[c] = -1; rowdone[c] = false;
+            if (c < cw_used && r < R) {
+                double mn = INF; int arg = 0;
+                for (int j = 0; j < Cn; ++j) {
+                    const double g = use_matrix ? G[r * Cn + j] : gain(r, j);
+                    if (g < mn) { mn = g; arg = j; }
+                }
+                u[c] = mn; myarg[c] = arg;
+                atomicMin(&owner[arg], r);
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < CW; ++c) {
+            if (myarg[c] >= 0) rowdone[c] = owner[myarg[c]] == lane + 64 * c;
+            const int j = lane + 64 * c;
+            if (c < cw_used && j < Cn) { const int o = owner[j]; prow[c] = (o != 0x7fffffff) ? o : -1; }
+        }
+    }
     for (int i = 0; i < R && !failed; ++i) {
+        {
+            int dn = 0;
+#pragma unroll
+            for (int c = 0; c < CW; ++c)
+                if (c == (i >> 6)) dn = (int)rl32((u32)(rowdone[c] ? 1 : 0), i & 63);
+            if (dn) continue;
+        }
 #pragma unroll
         for (int c = 0; c < CW; ++c) { minv[c] = INF; used[c] = false; rowin[c] = (lane + 64 * c) == i; }
         int i0 = i, j0 = -1;            // j0 = -1 is the virtual start column holding row i
@@ -199,15 +236,20 @@ wasserstein_kernel(const double* __restrict__ dgm_a, const int* __restrict__ cnt
             }
             const double delta = wave_min_f64_dpp(best);
             ++nsteps;
-            // first column attaining delta
-            int j1 = -1;
+            // a column attaining delta; ties go to an unassigned column (ends the path at once),
+            // the rule scipy's linear_sum_assignment uses too
+            int j1 = -1, j1free = -1;
 #pragma unroll
             for (int c = CW - 1; c >= 0; --c) {
                 if (c >= cw_used) continue;
                 const int j = lane + 64 * c;
-                const u64 bal = __ballot(j < Cn && !used[c] && minv[c] == delta);
+                const bool at = j < Cn && !used[c] && minv[c] == delta;
+                const u64 bal = __ballot(at);
+                const u64 balf = __ballot(at && prow[c] < 0);
                 if (bal) j1 = 64 * c + __builtin_ctzll(bal);
+                if (balf) j1free = 64 * c + __builtin_ctzll(balf);
             }
+            if (j1free >= 0) j1 = j1free;
             if (j1 < 0 || !(delta < INF) || ++steps > Cn + 2) { failed = true; break; }
             // dual update: rows in the tree, used / unused columns
 #pragma unroll
@@ -297,7 +339,7 @@ tda_status launch_wasserstein(tda_ctx* ctx, const double* dgm_a, const int* cnt_
     const int lo = cap_a < cap_b ? cap_a : cap_b, hi = cap_a < cap_b ? cap_b : cap_a;
     const int max_rows = lo, max_cols = hi;
     if (max_cols > 512) TDA_FAIL(ctx, TDA_ERR_UNSUPPORTED, "diagrams with more than 512 rows are not supported");
-    const size_t vec_bytes = (size_t)(4 * max_rows + 3 * max_cols) * 8;
+    const size_t vec_bytes = (size_t)(4 * max_rows + 3 * max_cols + ((max_cols + 1) >> 1)) * 8;
     const size_t mat_bytes = (size_t)max_rows * max_cols * 8;
     // LDS budget for the per-pair cost matrix: whole matrix if small, else 48 KB (6144 entries:
     // enough for 46 x 123 H0 pairs); pairs that do not fit evaluate costs on the fly
