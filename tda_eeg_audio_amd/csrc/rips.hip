@@ -213,14 +213,14 @@ struct RipsLayout {
 
 // misc block (byte offsets inside off_misc)
 #define MISC_COMP 0                        // int comp[128]
-#define MISC_BRANK 512                     // int brank[256]
-#define MISC_BKEY (512 + 1024)             // float bkey[256]
-#define MISC_CAND (512 + 2048)             // u64 cand[8]
-#define MISC_WV (512 + 2048 + 64)          // Psi<4> scratch
-#define MISC_MIN (512 + 2048 + 96)         // u32 minkey
-#define MISC_DONE (512 + 2048 + 112)       // u8 done[NT_MAX]
-#define MISC_CKEY (512 + 2048 + 112 + NT_MAX)   // float ckey[NT_MAX]: lengths of this chunk's candidate edges
-#define MISC_BYTES (512 + 2048 + 112 + NT_MAX + 4 * NT_MAX)
+#define MISC_BRANK 512                     // int brank[512]   (up to 8 class words)
+#define MISC_BKEY (512 + 2048)             // float bkey[512]
+#define MISC_CAND (512 + 4096)             // u64 cand[8]
+#define MISC_WV (512 + 4096 + 64)          // Psi<8> scratch
+#define MISC_MIN (512 + 4096 + 128)        // u32 minkey
+#define MISC_DONE (512 + 4096 + 144)       // u8 done[NT_MAX]
+#define MISC_CKEY (512 + 4096 + 144 + NT_MAX)   // float ckey[NT_MAX]: lengths of this chunk's candidate edges
+#define MISC_BYTES (512 + 4096 + 144 + NT_MAX + 4 * NT_MAX)
 
 // ---------------------------------------------------------------------------------
 // The sweep (phase P3).  KEYFN(r, a, b) returns the float32 length of sorted edge r = (a,b).
@@ -244,7 +244,7 @@ __device__ void rips_sweep(int n, int E, int Ev, const u16* ord, const u16* rank
 
     for (int e = tid; e < E; e += NT) psi[e] = pzero<W>();
     if (tid < 128) comp[tid] = tid;
-    if (tid < 64 * W) { brank[tid] = -1; bkey[tid] = 0.f; }
+    for (int i = tid; i < 64 * W; i += NT) { brank[i] = -1; bkey[i] = 0.f; }
     __syncthreads();
 
     u64 alive[W];
@@ -505,11 +505,13 @@ struct KeyFromLds {
 template <int NT, int NVW, int W>
 __global__ void __launch_bounds__(NT)
 rips_dm_kernel(const double* __restrict__ dm, int n_win, int n, float thresh, int symmetrise, RipsLayout L,
-               RipsOut out)
+               RipsOut out, int retry_only)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int win = blockIdx.x;
     if (win >= n_win) return;
+    // retry pass with a wider class vector: only windows the previous pass flagged
+    if (retry_only && !(out.status[win] & TDA_WIN_CLASS_OVERFLOW)) return;
     const int tid = threadIdx.x;
     const int E = tri2(n);
     int npad = 2 * NT;
@@ -773,7 +775,7 @@ static tda_status order_h1(tda_ctx* ctx, double* h1, int h1_cap, int* h1_cnt, in
 
 template <int NVW, int W>
 static tda_status launch_dm_t(tda_ctx* ctx, const double* dm, int n_win, int n, float thresh, int symmetrise,
-                              RipsOut out, hipStream_t st)
+                              RipsOut out, hipStream_t st, int retry_only = 0)
 {
     const int NT = 256;
     const RipsLayout L = make_layout(n, W, n * (n - 1) / 2 * 4, NT);
@@ -781,7 +783,8 @@ static tda_status launch_dm_t(tda_ctx* ctx, const double* dm, int n_win, int n, 
     if (L.total > 48 * 1024)
         TDA_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, L.total));
-    hipLaunchKernelGGL(kern, dim3(n_win), dim3(NT), L.total, st, dm, n_win, n, thresh, symmetrise, L, out);
+    hipLaunchKernelGGL(kern, dim3(n_win), dim3(NT), L.total, st, dm, n_win, n, thresh, symmetrise, L, out,
+                       retry_only);
     TDA_HIP(ctx, hipGetLastError());
     return TDA_OK;
 }
@@ -805,9 +808,20 @@ tda_status launch_rips_dm(tda_ctx* ctx, const double* dm, int n_win, int n, doub
         if (W == 1) rc = launch_dm_t<1, 1>(ctx, dm, n_win, n, th, symmetrise, out, st);
         else if (W == 2) rc = launch_dm_t<1, 2>(ctx, dm, n_win, n, th, symmetrise, out, st);
         else rc = launch_dm_t<1, 4>(ctx, dm, n_win, n, th, symmetrise, out, st);
+        // widening retries: windows that ran out of class bits are redone with 2x, 4x the bits while
+        // the table still fits LDS (n <= 47: 512 bits cover the theoretical maximum of 506 alive
+        // classes).  A retry launch whose windows are all fine exits at once.
+        for (int Wr = 2 * W; rc == TDA_OK && Wr <= 8; Wr *= 2) {
+            if (make_layout(n, Wr, n * (n - 1) / 2 * 4, 256).total > LDS_MAX) break;
+            if (Wr == 2) rc = launch_dm_t<1, 2>(ctx, dm, n_win, n, th, symmetrise, out, st, 1);
+            else if (Wr == 4) rc = launch_dm_t<1, 4>(ctx, dm, n_win, n, th, symmetrise, out, st, 1);
+            else rc = launch_dm_t<1, 8>(ctx, dm, n_win, n, th, symmetrise, out, st, 1);
+        }
     } else {
         if (W == 1) rc = launch_dm_t<2, 1>(ctx, dm, n_win, n, th, symmetrise, out, st);
         else rc = launch_dm_t<2, 2>(ctx, dm, n_win, n, th, symmetrise, out, st);
+        if (rc == TDA_OK && W == 1 && make_layout(n, 2, n * (n - 1) / 2 * 4, 256).total <= LDS_MAX)
+            rc = launch_dm_t<2, 2>(ctx, dm, n_win, n, th, symmetrise, out, st, 1);
     }
     if (rc != TDA_OK) return rc;
     return order_h1(ctx, h1, h1_cap, h1_cnt, n_win, st);

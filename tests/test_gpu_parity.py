@@ -149,28 +149,56 @@ def test_rips_dm_symmetrise_semantics(ctx, golden):
     assert _same_multiset(h0[0], o[0]) and _same_multiset(h1[0], o[1])
 
 
-def test_rips_class_overflow_is_reported_not_silent(ctx):
+def test_rips_class_capacity_widens_automatically(ctx):
+    """64 class bits are too few for white-noise windows (up to ~70 classes alive at once): the
+    widening retry launches (128, 256, 512 bits) must repair exactly the flagged windows."""
     W = synth.eeg_windows(16, seed=3, kind="white")
     dist = engine.corr_dist_batch(W, want_corr=False, ctx=ctx)
-    ctx.set_class_words(1, 1)
-    try:
-        h0, h1, st = engine.rips_dm_batch(dist, ctx=ctx)
-        for w in range(16):
-            o = port.rips_dm(dist[w])
-            if st[w] == 0:
-                assert _same_multiset(h1[w], o[1])
-            else:
-                assert st[w] & 2
-    finally:
-        ctx.set_class_words(2, 1)
-    ctx.set_class_words(4, 1)
-    try:
-        h0, h1, st = engine.rips_dm_batch(dist, ctx=ctx)
-        assert not st.any()
-        for w in range(16):
-            assert _same_multiset(h1[w], port.rips_dm(dist[w])[1])
-    finally:
-        ctx.set_class_words(2, 1)
+    for words in (1, 2, 4):
+        ctx.set_class_words(words, 1)
+        try:
+            h0, h1, st = engine.rips_dm_batch(dist, ctx=ctx)
+            assert not st.any(), (words, st)
+            for w in range(16):
+                o = port.rips_dm(dist[w])
+                assert _same_multiset(h0[w], o[0]) and _same_multiset(h1[w], o[1]), (words, w)
+        finally:
+            ctx.set_class_words(2, 1)
+
+
+def test_rips_worst_case_class_count_n47(ctx):
+    """Complete bipartite K(23,24) at distance 1, everything else at distance 2 - with thresh 1.5
+    there are 23*24 - 46 = 506 essential H1 classes alive at once (the maximum for 47 points)."""
+    n = 47
+    side = np.arange(n) < 23
+    d = np.where(side[:, None] != side[None, :], 1.0, 2.0)
+    d = d + np.random.default_rng(0).random((n, n)) * 1e-3          # break ties
+    d = (d + d.T) / 2
+    np.fill_diagonal(d, 0)
+    h0, h1, st = engine.rips_dm_batch(d[None], thresh=1.5, h1_cap=1024, ctx=ctx)
+    assert st[0] == 0 and len(h1[0]) == 506 and np.isinf(h1[0][:, 1]).all()
+    o = port.rips_dm(d, thresh=1.5)
+    assert _same_multiset(h0[0], o[0]) and _same_multiset(h1[0], o[1])
+    # and with the full threshold every one of them dies
+    h0, h1, st = engine.rips_dm_batch(d[None], thresh=3.0, h1_cap=1024, ctx=ctx)
+    o = port.rips_dm(d, thresh=3.0)
+    assert st[0] == 0 and _same_multiset(h1[0], o[1])
+
+
+def test_cloud_class_overflow_is_reported_not_silent(ctx):
+    """Point clouds above 112 points have one class word only (LDS); a cloud with more than 64
+    classes alive at once must be FLAGGED, never silently wrong."""
+    k = 60
+    ang = np.linspace(0, 2 * np.pi, k, endpoint=False)
+    a = np.stack([np.cos(ang), np.sin(ang), np.zeros(k)], 1)
+    b = np.stack([np.cos(ang + np.pi / k), np.sin(ang + np.pi / k), np.full(k, 0.9)], 1)
+    pc = np.concatenate([a, b])                      # two rings of 60: a "cylinder" graph, many squares
+    h0, h1, st = engine.cloud_rips_batch(pc[None], normalise=False, thresh=0.95, h1_cap=1024, ctx=ctx)
+    o = port.rips_f32(port.cloud_dm(pc).astype(np.float32), thresh=0.95)
+    if st[0] == 0:
+        assert _same_multiset(h1[0], o[1])
+    else:
+        assert st[0] & 2
 
 
 def test_rips_h1_truncation_flag(ctx):
