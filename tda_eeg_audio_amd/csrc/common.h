@@ -88,6 +88,16 @@ __device__ __forceinline__ int wave_max_i32_dpp(int v)
     return __builtin_amdgcn_readlane(v, 63);
 }
 
+__device__ __forceinline__ u32 wave_min_u32_dpp(u32 x)
+{
+    int v = (int)(x ^ 0x80000000u);          // unsigned order as signed
+#define TDA_DPP_I32_(CTRL, RM) { const int o__ = __builtin_amdgcn_update_dpp(v, v, CTRL, RM, 0xF, false); v = o__ < v ? o__ : v; }
+    TDA_DPP_I32_(0xB1, 0xF) TDA_DPP_I32_(0x4E, 0xF) TDA_DPP_I32_(0x141, 0xF) TDA_DPP_I32_(0x140, 0xF)
+    TDA_DPP_I32_(0x142, 0xA) TDA_DPP_I32_(0x143, 0xC)
+#undef TDA_DPP_I32_
+    return (u32)__builtin_amdgcn_readlane(v, 63) ^ 0x80000000u;
+}
+
 // order-preserving float32 <-> uint32 (handles negative values; NaN sorts last)
 __device__ __forceinline__ u32 f32_sortable(float f)
 {

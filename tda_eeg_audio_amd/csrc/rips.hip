@@ -36,7 +36,7 @@
 // No MFMA: this is irregular integer work; the roofline that binds it is LDS latency/issue.
 #include "common.h"
 
-#define NT_MAX 512            // largest workgroup (point-cloud flavour); distance-matrix flavour uses 256
+#define NT_MAX 1024           // largest workgroup (point-cloud flavour); distance-matrix flavour uses 256
 #define RANK_NONE 0x7fffu
 
 // ---- optional phase profiling (make PROFILE=1): cycle sums per phase over all windows ----
@@ -64,6 +64,17 @@ extern "C" __attribute__((visibility("default"))) int tda_profile_read(unsigned 
 #define PROF_MARK(i) do {} while (0)
 #define PROF_COUNT(i, v) do {} while (0)
 #endif
+
+#define WAVE_SYNC()                                            \
+    do {                                                       \
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); \
+        __builtin_amdgcn_wave_barrier();                       \
+    } while (0)
+
+struct SweepShared {
+    u64 alive[8];
+    int k0, merges, status, clen;
+};
 
 template <int W>
 struct __attribute__((aligned(8))) Psi {
@@ -215,12 +226,14 @@ struct RipsLayout {
 #define MISC_COMP 0                        // int comp[128]
 #define MISC_BRANK 512                     // int brank[512]   (up to 8 class words)
 #define MISC_BKEY (512 + 2048)             // float bkey[512]
-#define MISC_CAND (512 + 4096)             // u64 cand[8]
-#define MISC_WV (512 + 4096 + 64)          // Psi<8> scratch
-#define MISC_MIN (512 + 4096 + 128)        // u32 minkey
-#define MISC_DONE (512 + 4096 + 144)       // u8 done[NT_MAX]
-#define MISC_CKEY (512 + 4096 + 144 + NT_MAX)   // float ckey[NT_MAX]: lengths of this chunk's candidate edges
-#define MISC_BYTES (512 + 4096 + 144 + NT_MAX + 4 * NT_MAX)
+#define MISC_CAND (512 + 4096)             // u64 cand[16]
+#define MISC_WV (512 + 4096 + 128)         // Psi<8> scratch
+#define MISC_MIN (512 + 4096 + 192)        // u32 minkey
+#define MISC_DONE (512 + 4096 + 208)       // u8 done[NT_MAX]
+#define MISC_CKEY (512 + 4096 + 208 + NT_MAX)   // float ckey[NT_MAX]: lengths of this chunk's candidate edges
+#define MISC_SHARED (512 + 4096 + 208 + NT_MAX + 4 * NT_MAX)   // SweepShared (96 B)
+#define MISC_SLOTS (MISC_SHARED + 96)                        // KillSlot<8>[16]: per-wave earliest hit
+#define MISC_BYTES (MISC_SLOTS + 16 * 80)
 
 // ---------------------------------------------------------------------------------
 // The sweep (phase P3).  KEYFN(r, a, b) returns the float32 length of sorted edge r = (a,b).
@@ -241,6 +254,7 @@ __device__ void rips_sweep(int n, int E, int Ev, const u16* ord, const u16* rank
     u32* minkey = reinterpret_cast<u32*>(misc + MISC_MIN);
     unsigned char* done = misc + MISC_DONE;
     float* ckey = reinterpret_cast<float*>(misc + MISC_CKEY);
+    SweepShared* shared = reinterpret_cast<SweepShared*>(misc + MISC_SHARED);
 
     for (int e = tid; e < E; e += NT) psi[e] = pzero<W>();
     if (tid < 128) comp[tid] = tid;
@@ -251,6 +265,7 @@ __device__ void rips_sweep(int n, int E, int Ev, const u16* ord, const u16* rank
 #pragma unroll
     for (int c = 0; c < W; ++c) alive[c] = 0;
     int k0 = 0, k1 = 0, merges = 0, status = 0;
+    int compA = lane, compB = lane + 64;     // component labels of vertices lane / lane+64 (used by wave 0)
 
     int clen = NT;
     PROF_BEGIN();
@@ -263,23 +278,26 @@ __device__ void rips_sweep(int n, int E, int Ev, const u16* ord, const u16* rank
         if (valid) { const u32 pk = ord[r]; a = (int)(pk >> 8); b = (int)(pk & 255u); }
         const int tab = tri2(a) + b;
         // ---- a. common-neighbour mask from the rank rows of a and b ----
-        u64 M[NVW];
+        u64 M[NVW], M0[NVW];     // M: common neighbours before edge r; M0: those already common at chunk start
 #pragma unroll
-        for (int w = 0; w < NVW; ++w) M[w] = 0;
+        for (int w = 0; w < NVW; ++w) { M[w] = 0; M0[w] = 0; }
         if (valid) {
             const u64* ra = reinterpret_cast<const u64*>(rank + a * ns);
             const u64* rb = reinterpret_cast<const u64*>(rank + b * ns);
             const u64 H = 0x8000800080008000ull;
             const u64 RR = (u64)r * 0x0001000100010001ull;
+            const u64 RR0 = (u64)r0 * 0x0001000100010001ull;
             const int groups = (n + 3) >> 2;
 #pragma unroll 4
             for (int g = 0; g < groups; ++g) {
-                const u64 xa = ra[g], xb = rb[g];
+                const u64 xa = ra[g] | H, xb = rb[g] | H;
                 // per 16-bit field: (x|0x8000) - r never borrows; bit 15 clear  <=>  x < r
-                const u64 t = ~(((xa | H) - RR) | ((xb | H) - RR)) & H;
+                const u64 t = ~((xa - RR) | (xb - RR)) & H;
+                const u64 t0 = ~((xa - RR0) | (xb - RR0)) & H;
                 const u64 nib = ((t >> 15) & 1ull) | ((t >> 30) & 2ull) | ((t >> 45) & 4ull) | ((t >> 60) & 8ull);
-                if (NVW == 1) M[0] |= nib << (4 * g);
-                else M[(g >> 4) & (NVW - 1)] |= nib << (4 * (g & 15));
+                const u64 nib0 = ((t0 >> 15) & 1ull) | ((t0 >> 30) & 2ull) | ((t0 >> 45) & 4ull) | ((t0 >> 60) & 8ull);
+                if (NVW == 1) { M[0] |= nib << (4 * g); M0[0] |= nib0 << (4 * g); }
+                else { M[(g >> 4) & (NVW - 1)] |= nib << (4 * (g & 15)); M0[(g >> 4) & (NVW - 1)] |= nib0 << (4 * (g & 15)); }
             }
         }
         u64 many = 0;
@@ -295,62 +313,90 @@ __device__ void rips_sweep(int n, int E, int Ev, const u16* ord, const u16* rank
         if (is_cand) ckey[tid] = keyfn(r, a, b);     // every candidate needs its length (H0 death / H1 birth)
         done[tid] = 0;
         __syncthreads();
-        for (int wv = 0; wv < NT / 64; ++wv) {
-            u64 cb = cand[wv];
-            while (cb) {
-                const int q = 64 * wv + __builtin_ctzll(cb);
-                cb &= cb - 1;
-                const int rq = r0 + q;
-                const u32 pk = ord[rq];
-                const int qa = (int)(pk >> 8), qb = (int)(pk & 255u);
-                const int ca = comp[qa], cbb = comp[qb];
-                const float key = ckey[q];
-                if (ca != cbb) {
-                    __syncthreads();
-                    if (tid < n && comp[tid] == cbb) comp[tid] = ca;
-                    ++merges;
-                    if (key != 0.0f) {
-                        if (k0 < h0_cap && tid == 0) { h0[2 * k0] = 0.0; h0[2 * k0 + 1] = (double)key; }
-                        ++k0;
-                    }
-                    __syncthreads();
-                } else {
-                    int cw = -1, bit = 0;
+        // wave 0 alone walks the candidates in rank order (the other waves would only replay the
+        // same scalar work and fight for issue slots); LDS accesses of one wave are in order
+        if (wave == 0) {
+            for (int g = 0; g < NT / 64 && !status && clen == NT; ++g) {
+                u64 cb = cand[g];
+                if (!cb) continue;
+                // this group's edges and lengths into registers: the walk below is LDS-free
+                const int rg = r0 + 64 * g + lane;
+                const u32 pkv = ord[rg < E ? rg : E - 1];
+                const u32 keyv = __float_as_uint(ckey[64 * g + lane]);
+                while (cb) {
+                    const int l = __builtin_ctzll(cb);
+                    cb &= cb - 1;
+                    const int q = 64 * g + l;
+                    const int rq = r0 + q;
+                    const u32 pk = rl32(pkv, l);
+                    const float key = __uint_as_float(rl32(keyv, l));
+                    const int qa = (int)(pk >> 8), qb = (int)(pk & 255u);
+                    const int ca = qa < 64 ? (int)rl32((u32)compA, qa) : (int)rl32((u32)compB, qa - 64);
+                    const int cbb = qb < 64 ? (int)rl32((u32)compA, qb) : (int)rl32((u32)compB, qb - 64);
+                    if (ca != cbb) {
+                        compA = compA == cbb ? ca : compA;
+                        compB = compB == cbb ? ca : compB;
+                        ++merges;
+                        if (key != 0.0f) {
+                            if (k0 < h0_cap && lane == 0) { h0[2 * k0] = 0.0; h0[2 * k0 + 1] = (double)key; }
+                            ++k0;
+                        }
+                    } else {
+                        int cw = -1, bit = 0;
 #pragma unroll
-                    for (int c = W - 1; c >= 0; --c) {
-                        const u64 fr = ~alive[c];
-                        if (fr) { cw = c; bit = __builtin_ctzll(fr); }
-                    }
-                    if (cw < 0) {
-                        // every class bit is in use: close the chunk just before this edge so that the
-                        // kills of the shortened chunk can free bits (capacity = classes alive at once)
-                        if (q == 0) status |= TDA_WIN_CLASS_OVERFLOW;
-                        else clen = q;
-                        break;
-                    }
-#pragma unroll
-                    for (int c = 0; c < W; ++c)
-                        if (c == cw) alive[c] |= (1ull << bit);
-                    if (tid == 0) {
-                        Psi<W> nv = pzero<W>();
+                        for (int c = W - 1; c >= 0; --c) {
+                            const u64 fr = ~alive[c];
+                            if (fr) { cw = c; bit = __builtin_ctzll(fr); }
+                        }
+                        if (cw < 0) {
+                            // every class bit is in use: close the chunk just before this edge so that the
+                            // kills of the shortened chunk can free bits (capacity = classes alive at once)
+                            if (q == 0) status |= TDA_WIN_CLASS_OVERFLOW;
+                            else clen = q;
+                            break;
+                        }
 #pragma unroll
                         for (int c = 0; c < W; ++c)
-                            if (c == cw) nv.w[c] = (1ull << bit);
-                        psi[tri2(qa) + qb] = nv;
-                        brank[64 * cw + bit] = rq;
-                        bkey[64 * cw + bit] = key;
+                            if (c == cw) alive[c] |= (1ull << bit);
+                        if (lane == 0) {
+                            Psi<W> nv = pzero<W>();
+#pragma unroll
+                            for (int c = 0; c < W; ++c)
+                                if (c == cw) nv.w[c] = (1ull << bit);
+                            psi[tri2(qa) + qb] = nv;
+                            brank[64 * cw + bit] = rq;
+                            bkey[64 * cw + bit] = key;
+                        }
                     }
                 }
             }
-            if (status || clen < NT) break;
+            if (lane == 0) {
+#pragma unroll
+                for (int c = 0; c < W; ++c) shared->alive[c] = alive[c];
+                shared->k0 = k0; shared->merges = merges; shared->status = status; shared->clen = clen;
+            }
         }
-        if (status) break;
         __syncthreads();
+#pragma unroll
+        for (int c = 0; c < W; ++c) alive[c] = shared->alive[c];
+        k0 = shared->k0; merges = shared->merges; status = shared->status; clen = shared->clen;
+        if (status) break;
         PROF_MARK(5);
         // ---- c. apparent edges: psi[e] = psi[a,v*] ^ psi[b,v*] ----
+        // apex of the triangle that kills the edge at once: ANY common neighbour is valid (the other
+        // triangles are verified below); prefer one whose two edges predate the chunk, so that
+        // psi[a,v*] and psi[b,v*] are final already and no in-chunk dependency arises
+        u64 many0 = 0;
+#pragma unroll
+        for (int w = 0; w < NVW; ++w) many0 |= M0[w];
         int vstar = 0;
-        if (NVW == 1 || M[0]) vstar = __builtin_ctzll(M[0] | (many ? 0ull : 1ull));
-        else vstar = 64 + __builtin_ctzll(M[NVW - 1]);
+        if (many0) {
+            if (NVW == 1 || M0[0]) vstar = __builtin_ctzll(M0[0]);
+            else vstar = 64 + __builtin_ctzll(M0[NVW - 1]);
+        } else if (many) {
+            if (NVW == 1 || M[0]) vstar = __builtin_ctzll(M[0]);
+            else vstar = 64 + __builtin_ctzll(M[NVW - 1]);
+        }
         const bool apparent = valid && many != 0 && tid < clen;
         int d1 = 0, d2 = 0, q1 = 0, q2 = 0;
         if (apparent) {
@@ -361,6 +407,7 @@ __device__ void rips_sweep(int n, int E, int Ev, const u16* ord, const u16* rank
         if (!apparent) done[tid] = 1;       // candidates (and idle lanes) are settled
         __syncthreads();
         Psi<W> base = pzero<W>();
+        // rounds: a lane is ready when both dependencies are settled (almost always at once, see v*)
         while (true) {
             bool ready = false;
             if (pending) ready = (q1 < 0 || done[q1]) && (q2 < 0 || done[q2]);
@@ -403,17 +450,30 @@ __device__ void rips_sweep(int n, int E, int Ev, const u16* ord, const u16* rank
                 if (!found) found = scan_word<W>(m2, 64, psi, base, a, b, ta_, tb_, cur_v, ia, ib);
                 if (!found) found = scan_word<W>(m3, 96, psi, base, a, b, ta_, tb_, cur_v, ia, ib);
             }
-            if (tid == 0) *minkey = 0xffffffffu;
-            __syncthreads();
-            const u32 mykey = ((u32)tid << 8) | (u32)cur_v;
-            if (found) atomicMin(minkey, mykey);
-            __syncthreads();
-            const u32 mk = *minkey;
+            // earliest non-trivial triangle: per wave on the DPP network, across waves through one
+            // LDS slot per wave (one barrier; slot writes of the next trip come after barrier B)
+            const u32 mykey = found ? (((u32)tid << 8) | (u32)cur_v) : 0xffffffffu;
+            const u32 wmin = wave_min_u32_dpp(mykey);
+            {
+                unsigned char* slot = misc + MISC_SLOTS + 80 * wave;
+                if (found && mykey == wmin) {
+                    *reinterpret_cast<u32*>(slot) = wmin;
+                    *reinterpret_cast<Psi<W>*>(slot + 8) = pxor(pxor(psi[ia], psi[ib]), base);
+                } else if (wmin == 0xffffffffu && lane == 0) {
+                    *reinterpret_cast<u32*>(slot) = 0xffffffffu;
+                }
+            }
+            __syncthreads();                                   // barrier A
+            u32 mk = 0xffffffffu;
+            int mwv = 0;
+#pragma unroll
+            for (int w8 = 0; w8 < NT / 64; ++w8) {
+                const u32 kk = *reinterpret_cast<const u32*>(misc + MISC_SLOTS + 80 * w8);
+                if (kk < mk) { mk = kk; mwv = w8; }
+            }
             if (mk == 0xffffffffu) break;
             // ---- kill: the earliest non-trivial triangle of the chunk ----
-            if (found && mykey == mk) *wvs = pxor(pxor(psi[ia], psi[ib]), base);
-            __syncthreads();
-            const Psi<W> wv = *wvs;
+            const Psi<W> wv = *reinterpret_cast<const Psi<W>*>(misc + MISC_SLOTS + 80 * mwv + 8);
             const int rk = r0 + (int)(mk >> 8);
             // youngest class of wv: lane i looks at bit i of every word (each wave redundantly)
             int candv = -1;
@@ -434,7 +494,6 @@ __device__ void rips_sweep(int n, int E, int Ev, const u16* ord, const u16* rank
                 if (k1 < h1_cap && tid == 0) { h1[2 * k1] = (double)ybirth; h1[2 * k1 + 1] = (double)key; }
                 ++k1;
             }
-            __syncthreads();
 #pragma unroll 4
             for (int e = tid; e < E; e += NT) {
                 Psi<W> p = psi[e];
@@ -447,7 +506,6 @@ __device__ void rips_sweep(int n, int E, int Ev, const u16* ord, const u16* rank
 #pragma unroll
             for (int c = 0; c < W; ++c)
                 if (c == ycw) alive[c] &= ~(1ull << ybit);
-            if (tid == 0) brank[64 * ycw + ybit] = -1;
             __syncthreads();
             PROF_COUNT(10, 1);
         }
@@ -790,6 +848,9 @@ static tda_status launch_dm_t(tda_ctx* ctx, const double* dm, int n_win, int n, 
 }
 
 static const int LDS_MAX = 160 * 1024;
+#ifndef CLOUD_NT
+#define CLOUD_NT 512           // workgroup size of the point-cloud flavour (one workgroup per CU: LDS)
+#endif
 
 tda_status launch_rips_dm(tda_ctx* ctx, const double* dm, int n_win, int n, double thresh, int symmetrise,
                           double* h0, int h0_cap, int* h0_cnt, double* h1, int h1_cap, int* h1_cnt, int* status,
@@ -832,10 +893,10 @@ static tda_status launch_cloud_t(tda_ctx* ctx, const double* src, const int* aux
                                  int dim, int subsample, int mode, int normalise, float thresh, int p_max,
                                  int* n_points, RipsOut out, hipStream_t st)
 {
-    const int NT = 512;
+    const int NT = CLOUD_NT;
     const RipsLayout L = make_layout(p_max, W, p_max * dim * 8, NT);
     if (L.total > LDS_MAX) TDA_FAIL(ctx, TDA_ERR_UNSUPPORTED, "point cloud too large for LDS");
-    auto kern = rips_cloud_kernel<512, W>;
+    auto kern = rips_cloud_kernel<CLOUD_NT, W>;
     if (L.total > 48 * 1024)
         TDA_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, L.total));
@@ -868,7 +929,7 @@ tda_status launch_rips_cloud(tda_ctx* ctx, const double* src, const int* aux, in
     const float th = (float)thresh;
     tda_status rc;
     int W = ctx->words_cloud;
-    while (W > 1 && make_layout(p_max, W, p_max * dim * 8, 512).total > LDS_MAX) W >>= 1;
+    while (W > 1 && make_layout(p_max, W, p_max * dim * 8, CLOUD_NT).total > LDS_MAX) W >>= 1;
     if (W == 1)
         rc = launch_cloud_t<1>(ctx, src, aux, n_win, n_t_or_pcap, dim, subsample, mode, normalise, th, p_max,
                                n_points, out, st);
