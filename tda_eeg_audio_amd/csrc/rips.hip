@@ -36,7 +36,7 @@
 // No MFMA: this is irregular integer work; the roofline that binds it is LDS latency/issue.
 #include "common.h"
 
-#define NT_MAX 1024           // largest workgroup (point-cloud flavour); distance-matrix flavour uses 256
+#define NT_MAX 512            // largest workgroup (point-cloud flavour); distance-matrix flavour uses 256
 #define RANK_NONE 0x7fffu
 
 // ---- optional phase profiling (make PROFILE=1): cycle sums per phase over all windows ----
@@ -76,30 +76,30 @@ struct SweepShared {
     int k0, merges, status, clen;
 };
 
-template <int W>
-struct __attribute__((aligned(8))) Psi {
-    u64 w[W];
+template <int W, typename WT>
+struct __attribute__((aligned(sizeof(WT)))) Psi {
+    WT w[W];            // W words of WT (u32: 32 classes per word, u64: 64)
 };
-template <int W>
-__device__ __forceinline__ Psi<W> pxor(Psi<W> a, Psi<W> b)
+template <int W, typename WT>
+__device__ __forceinline__ Psi<W, WT> pxor(Psi<W, WT> a, Psi<W, WT> b)
 {
-    Psi<W> r;
+    Psi<W, WT> r;
 #pragma unroll
     for (int i = 0; i < W; ++i) r.w[i] = a.w[i] ^ b.w[i];
     return r;
 }
-template <int W>
-__device__ __forceinline__ bool pnz(Psi<W> a)
+template <int W, typename WT>
+__device__ __forceinline__ bool pnz(Psi<W, WT> a)
 {
-    u64 o = 0;
+    WT o = 0;
 #pragma unroll
     for (int i = 0; i < W; ++i) o |= a.w[i];
     return o != 0;
 }
-template <int W>
-__device__ __forceinline__ Psi<W> pzero()
+template <int W, typename WT>
+__device__ __forceinline__ Psi<W, WT> pzero()
 {
-    Psi<W> r;
+    Psi<W, WT> r;
 #pragma unroll
     for (int i = 0; i < W; ++i) r.w[i] = 0;
     return r;
@@ -177,8 +177,8 @@ __device__ void bitonic_sort_lds(u64* S, int npad)
 // Scan the remaining triangles (a,b,v), v in one 32-bit mask word (vertices vbase..vbase+31), four
 // per trip (all eight LDS reads are issued before the first test).  Returns true at the first
 // non-trivial boundary class psi[a,v]^psi[b,v]^base and leaves the word positioned just after it.
-template <int W>
-__device__ __forceinline__ bool scan_word(u32& mw, const int vbase, const Psi<W>* psi, const Psi<W> base, int a, int b,
+template <int W, typename WT>
+__device__ __forceinline__ bool scan_word(u32& mw, const int vbase, const Psi<W, WT>* psi, const Psi<W, WT> base, int a, int b,
                                           int ta, int tb, int& cur_v, int& ia, int& ib)
 {
     while (mw) {
@@ -193,8 +193,8 @@ __device__ __forceinline__ bool scan_word(u32& mw, const int vbase, const Psi<W>
         const int jb = (v) < b ? tb + (v) : t##ja + b;
         TDA_IDX_(v0, ja0, jb0) TDA_IDX_(v1, ja1, jb1) TDA_IDX_(v2, ja2, jb2) TDA_IDX_(v3, ja3, jb3)
 #undef TDA_IDX_
-        const Psi<W> p0 = psi[ja0], q0 = psi[jb0], p1 = psi[ja1], q1 = psi[jb1];
-        const Psi<W> p2 = psi[ja2], q2 = psi[jb2], p3 = psi[ja3], q3 = psi[jb3];
+        const Psi<W, WT> p0 = psi[ja0], q0 = psi[jb0], p1 = psi[ja1], q1 = psi[jb1];
+        const Psi<W, WT> p2 = psi[ja2], q2 = psi[jb2], p3 = psi[ja3], q3 = psi[jb3];
         const bool n0 = pnz(pxor(pxor(p0, q0), base));
         const bool n1 = ok1 && pnz(pxor(pxor(p1, q1), base));
         const bool n2 = ok2 && pnz(pxor(pxor(p2, q2), base));
@@ -217,7 +217,7 @@ struct RipsOut {
 };
 
 struct RipsLayout {
-    int off_ord, off_rank, off_aux, off_misc;   // psi (and the sort array) start at 0
+    int off_rank, off_aux, off_misc;            // psi (and the sort array) start at 0
     int rank_stride;                            // u16 elements per rank row (multiple of 4)
     int total;
 };
@@ -233,38 +233,40 @@ struct RipsLayout {
 #define MISC_CKEY (512 + 4096 + 208 + NT_MAX)   // float ckey[NT_MAX]: lengths of this chunk's candidate edges
 #define MISC_SHARED (512 + 4096 + 208 + NT_MAX + 4 * NT_MAX)   // SweepShared (96 B)
 #define MISC_SLOTS (MISC_SHARED + 96)                        // KillSlot<8>[16]: per-wave earliest hit
-#define MISC_BYTES (MISC_SLOTS + 16 * 80)
+#define MISC_ORDC (MISC_SLOTS + 16 * 80)                     // u16 ordc[NT_MAX]: (a<<8|b) of this chunk's edges
+#define MISC_BYTES (MISC_ORDC + 2 * NT_MAX)
 
 // ---------------------------------------------------------------------------------
 // The sweep (phase P3).  KEYFN(r, a, b) returns the float32 length of sorted edge r = (a,b).
 // All control flow is workgroup-uniform; ord/rank/psi/misc live in LDS.
 // ---------------------------------------------------------------------------------
-template <int NT, int NVW, int W, class KEYFN>
-__device__ void rips_sweep(int n, int E, int Ev, const u16* ord, const u16* rank, int ns, Psi<W>* psi,
+template <int NT, int NVW, int W, typename WT, class KEYFN>
+__device__ void rips_sweep(int n, int E, int Ev, const u16* rank, int ns, Psi<W, WT>* psi,
                            unsigned char* misc, KEYFN keyfn, double* h0, int h0_cap, double* h1, int h1_cap,
                            int& out_k0, int& out_k1, int& out_status)
 {
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
-    int* comp = reinterpret_cast<int*>(misc + MISC_COMP);
     int* brank = reinterpret_cast<int*>(misc + MISC_BRANK);
     float* bkey = reinterpret_cast<float*>(misc + MISC_BKEY);
     u64* cand = reinterpret_cast<u64*>(misc + MISC_CAND);
-    Psi<W>* wvs = reinterpret_cast<Psi<W>*>(misc + MISC_WV);
-    u32* minkey = reinterpret_cast<u32*>(misc + MISC_MIN);
     unsigned char* done = misc + MISC_DONE;
     float* ckey = reinterpret_cast<float*>(misc + MISC_CKEY);
     SweepShared* shared = reinterpret_cast<SweepShared*>(misc + MISC_SHARED);
+    u16* ordc = reinterpret_cast<u16*>(misc + MISC_ORDC);
+    constexpr int WB = 8 * (int)sizeof(WT);          // class bits per word
 
-    for (int e = tid; e < E; e += NT) psi[e] = pzero<W>();
-    if (tid < 128) comp[tid] = tid;
-    for (int i = tid; i < 64 * W; i += NT) { brank[i] = -1; bkey[i] = 0.f; }
+    for (int e = tid; e < E; e += NT) psi[e] = pzero<W, WT>();
+    for (int i = tid; i < WB * W; i += NT) { brank[i] = -1; bkey[i] = 0.f; }
     __syncthreads();
 
-    u64 alive[W];
+    WT alive[W];
 #pragma unroll
     for (int c = 0; c < W; ++c) alive[c] = 0;
     int k0 = 0, k1 = 0, merges = 0, status = 0;
+    // walk of the rank matrix in 64-bit groups: item = (row a, group g); advanced without divisions
+    const int G = ns >> 2;
+    const int it_a0 = tid / G, it_g0 = tid - (tid / G) * G, it_da = NT / G, it_dg = NT - (NT / G) * G;
     int compA = lane, compB = lane + 64;     // component labels of vertices lane / lane+64 (used by wave 0)
 
     int clen = NT;
@@ -272,10 +274,29 @@ __device__ void rips_sweep(int n, int E, int Ev, const u16* ord, const u16* rank
     for (int r0 = 0; r0 < Ev && !status; r0 += clen) {
         clen = NT;
         PROF_MARK(15);
+        // the chunk's edges (a,b) are recovered from the rank matrix (no rank -> edge table is kept)
+        ordc[tid] = (u16)0x0100;
+        __syncthreads();
+        {
+            const u64* rank64 = reinterpret_cast<const u64*>(rank);
+            int ia_ = it_a0, ig_ = it_g0;
+            for (int item = tid; item < n * G; item += NT) {
+                const u64 x = rank64[item];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int d = (int)((x >> (16 * k)) & 0xffffull) - r0;
+                    const int bb = 4 * ig_ + k;
+                    if ((unsigned)d < (unsigned)NT && bb < ia_) ordc[d] = (u16)((ia_ << 8) | bb);
+                }
+                ia_ += it_da; ig_ += it_dg;
+                if (ig_ >= G) { ig_ -= G; ++ia_; }
+            }
+        }
+        __syncthreads();
         const int r = r0 + tid;
         const bool valid = r < Ev;
         int a = 1, b = 0;
-        if (valid) { const u32 pk = ord[r]; a = (int)(pk >> 8); b = (int)(pk & 255u); }
+        if (valid) { const u32 pk = ordc[tid]; a = (int)(pk >> 8); b = (int)(pk & 255u); }
         const int tab = tri2(a) + b;
         // ---- a. common-neighbour mask from the rank rows of a and b ----
         u64 M[NVW], M0[NVW];     // M: common neighbours before edge r; M0: those already common at chunk start
@@ -320,8 +341,7 @@ __device__ void rips_sweep(int n, int E, int Ev, const u16* ord, const u16* rank
                 u64 cb = cand[g];
                 if (!cb) continue;
                 // this group's edges and lengths into registers: the walk below is LDS-free
-                const int rg = r0 + 64 * g + lane;
-                const u32 pkv = ord[rg < E ? rg : E - 1];
+                const u32 pkv = ordc[64 * g + lane];
                 const u32 keyv = __float_as_uint(ckey[64 * g + lane]);
                 while (cb) {
                     const int l = __builtin_ctzll(cb);
@@ -345,8 +365,8 @@ __device__ void rips_sweep(int n, int E, int Ev, const u16* ord, const u16* rank
                         int cw = -1, bit = 0;
 #pragma unroll
                         for (int c = W - 1; c >= 0; --c) {
-                            const u64 fr = ~alive[c];
-                            if (fr) { cw = c; bit = __builtin_ctzll(fr); }
+                            const WT fr = (WT)~alive[c];
+                            if (fr) { cw = c; bit = __builtin_ctzll((u64)fr); }
                         }
                         if (cw < 0) {
                             // every class bit is in use: close the chunk just before this edge so that the
@@ -357,28 +377,28 @@ __device__ void rips_sweep(int n, int E, int Ev, const u16* ord, const u16* rank
                         }
 #pragma unroll
                         for (int c = 0; c < W; ++c)
-                            if (c == cw) alive[c] |= (1ull << bit);
+                            if (c == cw) alive[c] |= ((WT)1 << bit);
                         if (lane == 0) {
-                            Psi<W> nv = pzero<W>();
+                            Psi<W, WT> nv = pzero<W, WT>();
 #pragma unroll
                             for (int c = 0; c < W; ++c)
-                                if (c == cw) nv.w[c] = (1ull << bit);
+                                if (c == cw) nv.w[c] = ((WT)1 << bit);
                             psi[tri2(qa) + qb] = nv;
-                            brank[64 * cw + bit] = rq;
-                            bkey[64 * cw + bit] = key;
+                            brank[WB * cw + bit] = rq;
+                            bkey[WB * cw + bit] = key;
                         }
                     }
                 }
             }
             if (lane == 0) {
 #pragma unroll
-                for (int c = 0; c < W; ++c) shared->alive[c] = alive[c];
+                for (int c = 0; c < W; ++c) shared->alive[c] = (u64)alive[c];
                 shared->k0 = k0; shared->merges = merges; shared->status = status; shared->clen = clen;
             }
         }
         __syncthreads();
 #pragma unroll
-        for (int c = 0; c < W; ++c) alive[c] = shared->alive[c];
+        for (int c = 0; c < W; ++c) alive[c] = (WT)shared->alive[c];
         k0 = shared->k0; merges = shared->merges; status = shared->status; clen = shared->clen;
         if (status) break;
         PROF_MARK(5);
@@ -406,7 +426,7 @@ __device__ void rips_sweep(int n, int E, int Ev, const u16* ord, const u16* rank
         bool pending = apparent;
         if (!apparent) done[tid] = 1;       // candidates (and idle lanes) are settled
         __syncthreads();
-        Psi<W> base = pzero<W>();
+        Psi<W, WT> base = pzero<W, WT>();
         // rounds: a lane is ready when both dependencies are settled (almost always at once, see v*)
         while (true) {
             bool ready = false;
@@ -437,18 +457,18 @@ __device__ void rips_sweep(int n, int E, int Ev, const u16* ord, const u16* rank
         const int ta_ = tri2(a), tb_ = tri2(b);
         bool found = false;
         int cur_v = 0, ia = 0, ib = 0;
-        for (int guard = 0; guard <= 64 * W; ++guard) {
+        for (int guard = 0; guard <= WB * W; ++guard) {
             // resume / continue the scan
             if (found) {
                 base = psi[tab];
-                const Psi<W> y = pxor(pxor(psi[ia], psi[ib]), base);
+                const Psi<W, WT> y = pxor(pxor(psi[ia], psi[ib]), base);
                 found = pnz(y);
             }
-            if (!found) found = scan_word<W>(m0, 0, psi, base, a, b, ta_, tb_, cur_v, ia, ib);
-            if (!found) found = scan_word<W>(m1, 32, psi, base, a, b, ta_, tb_, cur_v, ia, ib);
+            if (!found) found = scan_word<W, WT>(m0, 0, psi, base, a, b, ta_, tb_, cur_v, ia, ib);
+            if (!found) found = scan_word<W, WT>(m1, 32, psi, base, a, b, ta_, tb_, cur_v, ia, ib);
             if (NVW == 2) {
-                if (!found) found = scan_word<W>(m2, 64, psi, base, a, b, ta_, tb_, cur_v, ia, ib);
-                if (!found) found = scan_word<W>(m3, 96, psi, base, a, b, ta_, tb_, cur_v, ia, ib);
+                if (!found) found = scan_word<W, WT>(m2, 64, psi, base, a, b, ta_, tb_, cur_v, ia, ib);
+                if (!found) found = scan_word<W, WT>(m3, 96, psi, base, a, b, ta_, tb_, cur_v, ia, ib);
             }
             // earliest non-trivial triangle: per wave on the DPP network, across waves through one
             // LDS slot per wave (one barrier; slot writes of the next trip come after barrier B)
@@ -458,7 +478,7 @@ __device__ void rips_sweep(int n, int E, int Ev, const u16* ord, const u16* rank
                 unsigned char* slot = misc + MISC_SLOTS + 80 * wave;
                 if (found && mykey == wmin) {
                     *reinterpret_cast<u32*>(slot) = wmin;
-                    *reinterpret_cast<Psi<W>*>(slot + 8) = pxor(pxor(psi[ia], psi[ib]), base);
+                    *reinterpret_cast<Psi<W, WT>*>(slot + 8) = pxor(pxor(psi[ia], psi[ib]), base);
                 } else if (wmin == 0xffffffffu && lane == 0) {
                     *reinterpret_cast<u32*>(slot) = 0xffffffffu;
                 }
@@ -473,22 +493,23 @@ __device__ void rips_sweep(int n, int E, int Ev, const u16* ord, const u16* rank
             }
             if (mk == 0xffffffffu) break;
             // ---- kill: the earliest non-trivial triangle of the chunk ----
-            const Psi<W> wv = *reinterpret_cast<const Psi<W>*>(misc + MISC_SLOTS + 80 * mwv + 8);
+            const Psi<W, WT> wv = *reinterpret_cast<const Psi<W, WT>*>(misc + MISC_SLOTS + 80 * mwv + 8);
             const int rk = r0 + (int)(mk >> 8);
             // youngest class of wv: lane i looks at bit i of every word (each wave redundantly)
             int candv = -1;
+            const int lb = lane & (WB - 1);
 #pragma unroll
             for (int c = 0; c < W; ++c)
-                if ((wv.w[c] >> lane) & 1ull) { const int br = brank[64 * c + lane]; candv = br > candv ? br : candv; }
+                if (lane < WB && ((wv.w[c] >> lb) & (WT)1)) { const int br = brank[WB * c + lb]; candv = br > candv ? br : candv; }
             const int best = wave_max_i32_dpp(candv);
             int ybit = 0, ycw = 0;
 #pragma unroll
             for (int c = W - 1; c >= 0; --c) {
-                const u64 bal = __ballot(((wv.w[c] >> lane) & 1ull) && brank[64 * c + lane] == best);
+                const u64 bal = __ballot(lane < WB && ((wv.w[c] >> lb) & (WT)1) && brank[WB * c + lb] == best);
                 if (bal) { ycw = c; ybit = __builtin_ctzll(bal); }
             }
-            const float ybirth = bkey[64 * ycw + ybit];
-            const u32 pkk = ord[rk];
+            const float ybirth = bkey[WB * ycw + ybit];
+            const u32 pkk = ordc[rk - r0];
             const float key = keyfn(rk, (int)(pkk >> 8), (int)(pkk & 255u));
             if (key > ybirth) {
                 if (k1 < h1_cap && tid == 0) { h1[2 * k1] = (double)ybirth; h1[2 * k1 + 1] = (double)key; }
@@ -496,16 +517,16 @@ __device__ void rips_sweep(int n, int E, int Ev, const u16* ord, const u16* rank
             }
 #pragma unroll 4
             for (int e = tid; e < E; e += NT) {
-                Psi<W> p = psi[e];
-                u64 sel = 0;
+                Psi<W, WT> p = psi[e];
+                WT sel = 0;
 #pragma unroll
                 for (int c = 0; c < W; ++c)
-                    if (c == ycw) sel = (p.w[c] >> ybit) & 1ull;
+                    if (c == ycw) sel = (p.w[c] >> ybit) & (WT)1;
                 if (sel) psi[e] = pxor(p, wv);
             }
 #pragma unroll
             for (int c = 0; c < W; ++c)
-                if (c == ycw) alive[c] &= ~(1ull << ybit);
+                if (c == ycw) alive[c] &= (WT)~((WT)1 << ybit);
             __syncthreads();
             PROF_COUNT(10, 1);
         }
@@ -520,11 +541,11 @@ __device__ void rips_sweep(int n, int E, int Ev, const u16* ord, const u16* rank
     }
 #pragma unroll
     for (int c = 0; c < W; ++c) {
-        u64 al = alive[c];
+        u64 al = (u64)alive[c];
         while (al) {
             const int bit = __builtin_ctzll(al);
             al &= al - 1;
-            if (k1 < h1_cap && tid == 0) { h1[2 * k1] = (double)bkey[64 * c + bit]; h1[2 * k1 + 1] = (double)INFINITY; }
+            if (k1 < h1_cap && tid == 0) { h1[2 * k1] = (double)bkey[WB * c + bit]; h1[2 * k1 + 1] = (double)INFINITY; }
             ++k1;
         }
     }
@@ -532,22 +553,44 @@ __device__ void rips_sweep(int n, int E, int Ev, const u16* ord, const u16* rank
     out_k0 = k0; out_k1 = k1; out_status = status;
 }
 
-// ord / rank / (skey) from the sorted composites; rank rows pre-filled with RANK_NONE
-template <int NT, bool WANT_KEYS>
-__device__ void unpack_sorted(const u64* S, int E, int Ev, int n, u16* ord, u16* rank, int ns, u32* skey)
+// rank matrix (and skey) from the sorted composites; rank rows pre-filled with RANK_NONE.
+// STAGE: the rank region overlaps the sorted array (psi narrower than 8 B per edge), so every
+// thread first pulls its <= 16 entries into registers.
+template <int NT, bool WANT_KEYS, bool STAGE>
+__device__ void unpack_sorted(const u64* S, int E, int Ev, int n, u16* rank, int ns, u32* skey)
 {
     const int tid = threadIdx.x;
+    constexpr int MAXPT = STAGE ? 16 : 1;
+    u64 held[MAXPT];
+    if (STAGE) {
+#pragma unroll
+        for (int k = 0; k < MAXPT; ++k) { const int e = tid + k * NT; held[k] = e < E ? S[e] : ~0ull; }
+        __syncthreads();
+    }
     for (int i = tid; i < n * ns; i += NT) rank[i] = (u16)RANK_NONE;
     __syncthreads();
-    for (int e = tid; e < E; e += NT) {
-        const u64 c = S[e];
-        const u32 pk = (u32)(c & 0xffffu);
-        const int a = (int)(pk >> 8), b = (int)(pk & 255u);
-        ord[e] = (u16)pk;
-        if (WANT_KEYS) skey[e] = (u32)(c >> 16);
-        const u16 rr = (e < Ev) ? (u16)e : (u16)RANK_NONE;
-        rank[a * ns + b] = rr;
-        rank[b * ns + a] = rr;
+    if (STAGE) {
+#pragma unroll
+        for (int k = 0; k < MAXPT; ++k) {
+            const int e = tid + k * NT;
+            if (e < E) {
+                const u32 pk = (u32)(held[k] & 0xffffu);
+                const int a = (int)(pk >> 8), b = (int)(pk & 255u);
+                const u16 rr = (e < Ev) ? (u16)e : (u16)RANK_NONE;
+                rank[a * ns + b] = rr;
+                rank[b * ns + a] = rr;
+            }
+        }
+    } else {
+        for (int e = tid; e < E; e += NT) {
+            const u64 c = S[e];
+            const u32 pk = (u32)(c & 0xffffu);
+            const int a = (int)(pk >> 8), b = (int)(pk & 255u);
+            if (WANT_KEYS) skey[e] = (u32)(c >> 16);
+            const u16 rr = (e < Ev) ? (u16)e : (u16)RANK_NONE;
+            rank[a * ns + b] = rr;
+            rank[b * ns + a] = rr;
+        }
     }
     __syncthreads();
 }
@@ -560,7 +603,7 @@ struct KeyFromLds {
     __device__ __forceinline__ float operator()(int r, int, int) const { return sortable_f32(skey[r]); }
 };
 
-template <int NT, int NVW, int W>
+template <int NT, int NVW, int W, typename WT>
 __global__ void __launch_bounds__(NT)
 rips_dm_kernel(const double* __restrict__ dm, int n_win, int n, float thresh, int symmetrise, RipsLayout L,
                RipsOut out, int retry_only)
@@ -575,8 +618,7 @@ rips_dm_kernel(const double* __restrict__ dm, int n_win, int n, float thresh, in
     int npad = 2 * NT;
     while (npad < E) npad <<= 1;
     u64* S = reinterpret_cast<u64*>(smem);
-    Psi<W>* psi = reinterpret_cast<Psi<W>*>(smem);
-    u16* ord = reinterpret_cast<u16*>(smem + L.off_ord);
+    Psi<W, WT>* psi = reinterpret_cast<Psi<W, WT>*>(smem);
     u16* rank = reinterpret_cast<u16*>(smem + L.off_rank);
     u32* skey = reinterpret_cast<u32*>(smem + L.off_aux);
     unsigned char* misc = smem + L.off_misc;
@@ -611,11 +653,11 @@ rips_dm_kernel(const double* __restrict__ dm, int n_win, int n, float thresh, in
     PROF_MARK(0);
     bitonic_sort_lds<NT>(S, npad);
     PROF_MARK(1);
-    unpack_sorted<NT, true>(S, E, Ev, n, ord, rank, L.rank_stride, skey);
+    unpack_sorted<NT, true, false>(S, E, Ev, n, rank, L.rank_stride, skey);
     PROF_MARK(2);
     int k0, k1, st;
     KeyFromLds kf{skey};
-    rips_sweep<NT, NVW, W>(n, E, Ev, ord, rank, L.rank_stride, psi, misc, kf,
+    rips_sweep<NT, NVW, W, WT>(n, E, Ev, rank, L.rank_stride, psi, misc, kf,
                        out.h0 + (size_t)win * out.h0_cap * 2, out.h0_cap,
                        out.h1 + (size_t)win * out.h1_cap * 2, out.h1_cap, k0, k1, st);
     PROF_MARK(3);
@@ -650,19 +692,20 @@ struct KeyFromPts {
     }
 };
 
-template <int NT, int W>
+template <int NT, int W, typename WT>
 __global__ void __launch_bounds__(NT)
 rips_cloud_kernel(const double* __restrict__ src, const int* __restrict__ tau_or_npts, int n_win,
                   int n_t_or_pcap, int dim, int subsample, int mode, int normalise, float thresh,
-                  RipsLayout L, int p_max, int* __restrict__ n_points, RipsOut out)
+                  RipsLayout L, int p_max, int* __restrict__ n_points, RipsOut out, int retry_only)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int win = blockIdx.x;
     if (win >= n_win) return;
+    // retry pass with a wider class vector: only windows the previous pass flagged
+    if (retry_only && !(out.status[win] & TDA_WIN_CLASS_OVERFLOW)) return;
     const int tid = threadIdx.x;
     u64* S = reinterpret_cast<u64*>(smem);
-    Psi<W>* psi = reinterpret_cast<Psi<W>*>(smem);
-    u16* ord = reinterpret_cast<u16*>(smem + L.off_ord);
+    Psi<W, WT>* psi = reinterpret_cast<Psi<W, WT>*>(smem);
     u16* rank = reinterpret_cast<u16*>(smem + L.off_rank);
     double* pts = reinterpret_cast<double*>(smem + L.off_aux);
     unsigned char* misc = smem + L.off_misc;
@@ -751,13 +794,14 @@ rips_cloud_kernel(const double* __restrict__ src, const int* __restrict__ tau_or
     PROF_MARK(0);
     bitonic_sort_lds<NT>(S, npad);
     PROF_MARK(1);
-    unpack_sorted<NT, false>(S, E, Ev, P, ord, rank, L.rank_stride, nullptr);
+    static_assert(NT * 16 >= TDA_MAX_POINTS * (TDA_MAX_POINTS - 1) / 2, "staging depth");
+    unpack_sorted<NT, false, (sizeof(WT) < 8)>(S, E, Ev, P, rank, L.rank_stride, nullptr);
     PROF_MARK(2);
     int k0, k1, st;
     if (P <= 64)
-        rips_sweep<NT, 1, W>(P, E, Ev, ord, rank, L.rank_stride, psi, misc, kf, h0, out.h0_cap, h1, out.h1_cap, k0, k1, st);
+        rips_sweep<NT, 1, W, WT>(P, E, Ev, rank, L.rank_stride, psi, misc, kf, h0, out.h0_cap, h1, out.h1_cap, k0, k1, st);
     else
-        rips_sweep<NT, 2, W>(P, E, Ev, ord, rank, L.rank_stride, psi, misc, kf, h0, out.h0_cap, h1, out.h1_cap, k0, k1, st);
+        rips_sweep<NT, 2, W, WT>(P, E, Ev, rank, L.rank_stride, psi, misc, kf, h0, out.h0_cap, h1, out.h1_cap, k0, k1, st);
     PROF_MARK(3);
     PROF_COUNT(8, 1);
     PROF_COUNT(9, E);
@@ -799,20 +843,19 @@ h1_order_kernel(double* __restrict__ h1, int h1_cap, const int* __restrict__ h1_
 // ---------------------------------------------------------------------------------
 static inline int align16(int x) { return (x + 15) & ~15; }
 
-static RipsLayout make_layout(int n, int W, int aux_bytes, int NT)
+static RipsLayout make_layout(int n, int psi_bytes_per_edge, int aux_bytes, int NT)
 {
     RipsLayout L;
     const int E = n * (n - 1) / 2;
     int npad = 2 * NT;
     while (npad < E) npad <<= 1;
-    const int psi_bytes = E * W * 8;
-    // the sort array may run past psi into ord/rank (written only after the sort); it must
+    const int psi_bytes = E * psi_bytes_per_edge;
+    // the sort array may run past psi into rank (written only after the sort); it must
     // stop before aux (point cloud: read after the sort) and misc
-    L.off_ord = align16(psi_bytes);
     int ns = (n + 3) & ~3;
     if ((ns & 7) == 0) ns += 4;                   // odd multiple of 4: spreads rows over LDS banks
     L.rank_stride = ns;
-    L.off_rank = align16(L.off_ord + E * 2);
+    L.off_rank = align16(psi_bytes);
     int after_rank = align16(L.off_rank + n * ns * 2);
     if (after_rank < npad * 8) after_rank = align16(npad * 8);
     L.off_aux = after_rank;
@@ -836,8 +879,8 @@ static tda_status launch_dm_t(tda_ctx* ctx, const double* dm, int n_win, int n, 
                               RipsOut out, hipStream_t st, int retry_only = 0)
 {
     const int NT = 256;
-    const RipsLayout L = make_layout(n, W, n * (n - 1) / 2 * 4, NT);
-    auto kern = rips_dm_kernel<256, NVW, W>;
+    const RipsLayout L = make_layout(n, W * 8, n * (n - 1) / 2 * 4, NT);
+    auto kern = rips_dm_kernel<256, NVW, W, u64>;
     if (L.total > 48 * 1024)
         TDA_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, L.total));
@@ -864,7 +907,7 @@ tda_status launch_rips_dm(tda_ctx* ctx, const double* dm, int n_win, int n, doub
     tda_status rc;
     int W = ctx->words_dm;
     // largest class capacity that still fits the 160 KiB LDS
-    while (W > 1 && make_layout(n, W, n * (n - 1) / 2 * 4, 256).total > LDS_MAX) W >>= 1;
+    while (W > 1 && make_layout(n, W * 8, n * (n - 1) / 2 * 4, 256).total > LDS_MAX) W >>= 1;
     if (n <= 64) {
         if (W == 1) rc = launch_dm_t<1, 1>(ctx, dm, n_win, n, th, symmetrise, out, st);
         else if (W == 2) rc = launch_dm_t<1, 2>(ctx, dm, n_win, n, th, symmetrise, out, st);
@@ -873,7 +916,7 @@ tda_status launch_rips_dm(tda_ctx* ctx, const double* dm, int n_win, int n, doub
         // the table still fits LDS (n <= 47: 512 bits cover the theoretical maximum of 506 alive
         // classes).  A retry launch whose windows are all fine exits at once.
         for (int Wr = 2 * W; rc == TDA_OK && Wr <= 8; Wr *= 2) {
-            if (make_layout(n, Wr, n * (n - 1) / 2 * 4, 256).total > LDS_MAX) break;
+            if (make_layout(n, Wr * 8, n * (n - 1) / 2 * 4, 256).total > LDS_MAX) break;
             if (Wr == 2) rc = launch_dm_t<1, 2>(ctx, dm, n_win, n, th, symmetrise, out, st, 1);
             else if (Wr == 4) rc = launch_dm_t<1, 4>(ctx, dm, n_win, n, th, symmetrise, out, st, 1);
             else rc = launch_dm_t<1, 8>(ctx, dm, n_win, n, th, symmetrise, out, st, 1);
@@ -881,27 +924,27 @@ tda_status launch_rips_dm(tda_ctx* ctx, const double* dm, int n_win, int n, doub
     } else {
         if (W == 1) rc = launch_dm_t<2, 1>(ctx, dm, n_win, n, th, symmetrise, out, st);
         else rc = launch_dm_t<2, 2>(ctx, dm, n_win, n, th, symmetrise, out, st);
-        if (rc == TDA_OK && W == 1 && make_layout(n, 2, n * (n - 1) / 2 * 4, 256).total <= LDS_MAX)
+        if (rc == TDA_OK && W == 1 && make_layout(n, 16, n * (n - 1) / 2 * 4, 256).total <= LDS_MAX)
             rc = launch_dm_t<2, 2>(ctx, dm, n_win, n, th, symmetrise, out, st, 1);
     }
     if (rc != TDA_OK) return rc;
     return order_h1(ctx, h1, h1_cap, h1_cnt, n_win, st);
 }
 
-template <int W>
+template <int W, typename WT>
 static tda_status launch_cloud_t(tda_ctx* ctx, const double* src, const int* aux, int n_win, int n_t_or_pcap,
                                  int dim, int subsample, int mode, int normalise, float thresh, int p_max,
-                                 int* n_points, RipsOut out, hipStream_t st)
+                                 int* n_points, RipsOut out, hipStream_t st, int retry_only)
 {
     const int NT = CLOUD_NT;
-    const RipsLayout L = make_layout(p_max, W, p_max * dim * 8, NT);
+    const RipsLayout L = make_layout(p_max, W * (int)sizeof(WT), p_max * dim * 8, NT);
     if (L.total > LDS_MAX) TDA_FAIL(ctx, TDA_ERR_UNSUPPORTED, "point cloud too large for LDS");
-    auto kern = rips_cloud_kernel<CLOUD_NT, W>;
+    auto kern = rips_cloud_kernel<CLOUD_NT, W, WT>;
     if (L.total > 48 * 1024)
         TDA_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, L.total));
     hipLaunchKernelGGL(kern, dim3(n_win), dim3(NT), L.total, st, src, aux, n_win, n_t_or_pcap, dim, subsample, mode,
-                       normalise, thresh, L, p_max, n_points, out);
+                       normalise, thresh, L, p_max, n_points, out, retry_only);
     TDA_HIP(ctx, hipGetLastError());
     return TDA_OK;
 }
@@ -927,15 +970,22 @@ tda_status launch_rips_cloud(tda_ctx* ctx, const double* src, const int* aux, in
     if (h0_cap < p_max) TDA_FAIL(ctx, TDA_ERR_INVALID, "h0_cap must be >= max points per cloud");
     RipsOut out{h0, h0_cap, h0_cnt, h1, h1_cap, h1_cnt, status};
     const float th = (float)thresh;
-    tda_status rc;
-    int W = ctx->words_cloud;
-    while (W > 1 && make_layout(p_max, W, p_max * dim * 8, CLOUD_NT).total > LDS_MAX) W >>= 1;
-    if (W == 1)
-        rc = launch_cloud_t<1>(ctx, src, aux, n_win, n_t_or_pcap, dim, subsample, mode, normalise, th, p_max,
-                               n_points, out, st);
-    else
-        rc = launch_cloud_t<2>(ctx, src, aux, n_win, n_t_or_pcap, dim, subsample, mode, normalise, th, p_max,
-                               n_points, out, st);
+    tda_status rc = TDA_OK;
+    // class capacity ladder: 32 bits (two workgroups per CU for 124-point clouds), then 64, then 128
+    // while the table fits LDS; each wider pass only redoes the windows the previous one flagged
+    const bool fits128 = make_layout(p_max, 16, p_max * dim * 8, CLOUD_NT).total <= LDS_MAX;
+    int first = 1;
+    if (ctx->words_cloud == 1) {
+        rc = launch_cloud_t<1, u32>(ctx, src, aux, n_win, n_t_or_pcap, dim, subsample, mode, normalise, th, p_max,
+                                    n_points, out, st, 0);
+        first = 0;
+    }
+    if (rc == TDA_OK)
+        rc = launch_cloud_t<1, u64>(ctx, src, aux, n_win, n_t_or_pcap, dim, subsample, mode, normalise, th, p_max,
+                                    n_points, out, st, first ? 0 : 1);
+    if (rc == TDA_OK && fits128)
+        rc = launch_cloud_t<2, u64>(ctx, src, aux, n_win, n_t_or_pcap, dim, subsample, mode, normalise, th, p_max,
+                                    n_points, out, st, 1);
     if (rc != TDA_OK) return rc;
     return order_h1(ctx, h1, h1_cap, h1_cnt, n_win, st);
 }

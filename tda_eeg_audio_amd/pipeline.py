@@ -43,6 +43,7 @@ class Workspace:
         self.fa1 = torch.empty((n_win, 11), **f64)
         self.result = torch.empty((self.n_seg, RESULT_COLS), **f64)
         self.n_win_seg = torch.from_numpy(np.diff(seg_off).astype(np.float64)).to(device)
+        self.side_stream = torch.cuda.Stream(device=device)
 
 
 def run_step(eeg_win, audio_win, ws, ctx=None, max_lag=125, timers=None):
@@ -60,13 +61,21 @@ def run_step(eeg_win, audio_win, ws, ctx=None, max_lag=125, timers=None):
         e.record()
         return r
 
-    stage("corr_dist", lambda: engine.corr_dist_dev(eeg_win, ws.dist, None, ctx=ctx))
-    stage("rips_eeg", lambda: engine.rips_dm_dev(ws.dist, ws.eeg, ctx=ctx))
+    # The EEG chain (corr->dist->Rips) and the audio chain (tau->Takens->Rips) are independent until
+    # the Wasserstein step: the EEG kernels (31 KB LDS per workgroup) run on a side stream and
+    # co-reside on the CUs with the audio kernel (113 KB), filling its idle issue slots.
+    main = torch.cuda.current_stream()
+    side = ws.side_stream
+    side.wait_stream(main)
+    with torch.cuda.stream(side):
+        stage("corr_dist", lambda: engine.corr_dist_dev(eeg_win, ws.dist, None, ctx=ctx))
+        stage("rips_eeg", lambda: engine.rips_dm_dev(ws.dist, ws.eeg, ctx=ctx))
     # tau from the first selected window of each recording-band (cmp:83), broadcast to its windows
     first = audio_win.index_select(0, ws.first_idx)
     stage("tau", lambda: engine.tau_dev(first, max_lag, ws.tau_seg, ctx=ctx))
     tau_w = ws.tau_seg.index_select(0, ws.rec_id)
     stage("rips_audio", lambda: engine.takens_rips_dev(audio_win, tau_w, ws.aud, ctx=ctx))
+    main.wait_stream(side)
     stage("wasserstein_h0", lambda: engine.wasserstein_dev(ws.eeg.h0, ws.eeg.c0, ws.aud.h0, ws.aud.c0,
                                                            out_t=ws.w0, status_t=ws.ws0, ctx=ctx))
     stage("wasserstein_h1", lambda: engine.wasserstein_dev(ws.eeg.h1, ws.eeg.c1, ws.aud.h1, ws.aud.c1,
