@@ -73,8 +73,8 @@ __device__ __forceinline__ double uni_f64(double v, int lane)
         o__ = dpp_f64<0x142, 0xA>(v); v = OP(o__, v);  /* row_bcast:15        */      \
         o__ = dpp_f64<0x143, 0xC>(v); v = OP(o__, v);  /* row_bcast:31        */      \
     } while (0)
-#define TDA_MIN_(a, b) fmin((a), (b))
-#define TDA_MAX_(a, b) fmax((a), (b))
+#define TDA_MIN_(a, b) ((a) < (b) ? (a) : (b))
+#define TDA_MAX_(a, b) ((a) > (b) ? (a) : (b))
 #define TDA_ADD_(a, b) ((a) + (b))
 __device__ __forceinline__ double wave_min_f64_dpp(double v) { TDA_DPP_REDUCE_F64(v, TDA_MIN_); return uni_f64(v, 63); }
 __device__ __forceinline__ double wave_max_f64_dpp(double v) { TDA_DPP_REDUCE_F64(v, TDA_MAX_); return uni_f64(v, 63); }

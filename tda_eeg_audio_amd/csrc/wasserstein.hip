@@ -188,10 +188,15 @@ wasserstein_kernel(const double* __restrict__ dgm_a, const int* __restrict__ cnt
             const int r = lane + 64 * c;
             myarg[c] = -1; rowdone[c] = false;
             if (c < cw_used && r < R) {
+                // scan starts at column r (rotated): rows whose gains tie (typically all zero: the
+                // point prefers the diagonal) then claim DIFFERENT columns instead of all column 0
                 double mn = INF; int arg = 0;
-                for (int j = 0; j < Cn; ++j) {
+                int j = r < Cn ? r : 0;
+#pragma unroll 4
+                for (int t = 0; t < Cn; ++t) {
                     const double g = use_matrix ? G[r * Cn + j] : gain(r, j);
                     if (g < mn) { mn = g; arg = j; }
+                    j = (j + 1 == Cn) ? 0 : j + 1;
                 }
                 u[c] = mn; myarg[c] = arg;
                 atomicMin(&owner[arg], r);
@@ -222,17 +227,26 @@ wasserstein_kernel(const double* __restrict__ dgm_a, const int* __restrict__ cnt
 #pragma unroll
             for (int c = 0; c < CW; ++c)
                 if (c == (i0 >> 6)) ui0 = uni_f64(u[c], i0 & 63);
-            double best = INF;
+            // branch-free column update: all cost reads are issued first, invalid / used columns
+            // carry +inf candidates
+            double best = INF, gg[CW];
 #pragma unroll
             for (int c = 0; c < CW; ++c) {
                 if (c >= cw_used) break;
                 const int j = lane + 64 * c;
-                if (j < Cn && !used[c]) {
-                    const double g = use_matrix ? G[i0 * Cn + j] : gain(i0, j);
-                    const double cur = g - ui0 - v[c];
-                    if (cur < minv[c]) { minv[c] = cur; way[c] = j0; }
-                    best = fmin(minv[c], best);
-                }
+                const int jc = j < Cn ? j : Cn - 1;
+                gg[c] = use_matrix ? G[i0 * Cn + jc] : gain(i0, jc);
+            }
+#pragma unroll
+            for (int c = 0; c < CW; ++c) {
+                if (c >= cw_used) break;
+                const bool open = (lane + 64 * c) < Cn && !used[c];
+                const double cur = gg[c] - ui0 - v[c];
+                const bool upd = open && cur < minv[c];
+                minv[c] = upd ? cur : minv[c];
+                way[c] = upd ? j0 : way[c];
+                const double cnd = open ? minv[c] : INF;
+                best = cnd < best ? cnd : best;
             }
             const double delta = wave_min_f64_dpp(best);
             ++nsteps;
