@@ -234,7 +234,8 @@ struct RipsLayout {
 #define MISC_SHARED (512 + 4096 + 208 + NT_MAX + 4 * NT_MAX)   // SweepShared (96 B)
 #define MISC_SLOTS (MISC_SHARED + 96)                        // KillSlot<8>[16]: per-wave earliest hit
 #define MISC_ORDC (MISC_SLOTS + 16 * 80)                     // u16 ordc[NT_MAX]: (a<<8|b) of this chunk's edges
-#define MISC_BYTES (MISC_ORDC + 2 * NT_MAX)
+#define MISC_ADJ (MISC_ORDC + 2 * NT_MAX)                    // u64 adj[128][2]: adjacency bit rows at chunk start
+#define MISC_BYTES (MISC_ADJ + 128 * 16)
 
 // ---------------------------------------------------------------------------------
 // The sweep (phase P3).  KEYFN(r, a, b) returns the float32 length of sorted edge r = (a,b).
@@ -254,10 +255,12 @@ __device__ void rips_sweep(int n, int E, int Ev, const u16* rank, int ns, Psi<W,
     float* ckey = reinterpret_cast<float*>(misc + MISC_CKEY);
     SweepShared* shared = reinterpret_cast<SweepShared*>(misc + MISC_SHARED);
     u16* ordc = reinterpret_cast<u16*>(misc + MISC_ORDC);
+    u64* adj = reinterpret_cast<u64*>(misc + MISC_ADJ);      // adj[2*v + w]: neighbours of v among vertices 64w..64w+63
     constexpr int WB = 8 * (int)sizeof(WT);          // class bits per word
 
     for (int e = tid; e < E; e += NT) psi[e] = pzero<W, WT>();
     for (int i = tid; i < WB * W; i += NT) { brank[i] = -1; bkey[i] = 0.f; }
+    for (int i = tid; i < 256; i += NT) adj[i] = 0ull;
     __syncthreads();
 
     WT alive[W];
@@ -307,19 +310,18 @@ __device__ void rips_sweep(int n, int E, int Ev, const u16* rank, int ns, Psi<W,
             const u64* rb = reinterpret_cast<const u64*>(rank + b * ns);
             const u64 H = 0x8000800080008000ull;
             const u64 RR = (u64)r * 0x0001000100010001ull;
-            const u64 RR0 = (u64)r0 * 0x0001000100010001ull;
             const int groups = (n + 3) >> 2;
 #pragma unroll 4
             for (int g = 0; g < groups; ++g) {
                 const u64 xa = ra[g] | H, xb = rb[g] | H;
                 // per 16-bit field: (x|0x8000) - r never borrows; bit 15 clear  <=>  x < r
                 const u64 t = ~((xa - RR) | (xb - RR)) & H;
-                const u64 t0 = ~((xa - RR0) | (xb - RR0)) & H;
                 const u64 nib = ((t >> 15) & 1ull) | ((t >> 30) & 2ull) | ((t >> 45) & 4ull) | ((t >> 60) & 8ull);
-                const u64 nib0 = ((t0 >> 15) & 1ull) | ((t0 >> 30) & 2ull) | ((t0 >> 45) & 4ull) | ((t0 >> 60) & 8ull);
-                if (NVW == 1) { M[0] |= nib << (4 * g); M0[0] |= nib0 << (4 * g); }
-                else { M[(g >> 4) & (NVW - 1)] |= nib << (4 * (g & 15)); M0[(g >> 4) & (NVW - 1)] |= nib0 << (4 * (g & 15)); }
+                if (NVW == 1) M[0] |= nib << (4 * g);
+                else M[(g >> 4) & (NVW - 1)] |= nib << (4 * (g & 15));
             }
+#pragma unroll
+            for (int w = 0; w < NVW; ++w) M0[w] = adj[2 * a + w] & adj[2 * b + w];
         }
         u64 many = 0;
 #pragma unroll
@@ -442,17 +444,43 @@ __device__ void rips_sweep(int n, int E, int Ev, const u16* rank, int ns, Psi<W,
         }
         PROF_MARK(6);
         // ---- d. the other triangles of every apparent edge ----
+        // Link argument: if v and v' are common neighbours of (a,b) and adjacent to each other, the
+        // tetrahedron (a,b,v,v') shows that triangles (a,b,v) and (a,b,v') carry the same boundary
+        // class (its other two faces entered earlier, so their boundaries are already trivial).
+        // Hence only common neighbours OUTSIDE the connected component of v* in the link need a
+        // test.  The closure uses the adjacency rows of the chunk start (a subset of the true
+        // adjacency: it can only leave more vertices to test, never fewer than necessary).
         u32 m0, m1, m2 = 0u, m3 = 0u;
         {
-            u64 mm[NVW];
+            u64 rem[NVW];
 #pragma unroll
-            for (int w = 0; w < NVW; ++w) mm[w] = apparent ? M[w] : 0ull;
+            for (int w = 0; w < NVW; ++w) rem[w] = 0ull;
             if (apparent) {
-                if (NVW == 1 || vstar < 64) mm[0] &= ~(1ull << vstar);
-                else mm[NVW - 1] &= ~(1ull << (vstar - 64));
+                u64 comp[NVW], fr[NVW];
+#pragma unroll
+                for (int w = 0; w < NVW; ++w) comp[w] = 0ull;
+                if (NVW == 1 || vstar < 64) comp[0] = 1ull << vstar;
+                else comp[NVW - 1] = 1ull << (vstar - 64);
+#pragma unroll
+                for (int w = 0; w < NVW; ++w) { fr[w] = comp[w]; rem[w] = M[w] & ~comp[w]; }
+                for (int it = 0; it < 128; ++it) {
+                    u64 anyf = 0, anyr = 0;
+#pragma unroll
+                    for (int w = 0; w < NVW; ++w) { anyf |= fr[w]; anyr |= rem[w]; }
+                    if (!anyf || !anyr) break;
+                    int v;
+                    if (NVW == 1 || fr[0]) { v = __builtin_ctzll(fr[0]); fr[0] &= fr[0] - 1; }
+                    else { v = 64 + __builtin_ctzll(fr[NVW - 1]); fr[NVW - 1] &= fr[NVW - 1] - 1; }
+#pragma unroll
+                    for (int w = 0; w < NVW; ++w) {
+                        const u64 nb = adj[2 * v + w] & rem[w];
+                        rem[w] &= ~nb;
+                        fr[w] |= nb;
+                    }
+                }
             }
-            m0 = (u32)mm[0]; m1 = (u32)(mm[0] >> 32);
-            if (NVW == 2) { m2 = (u32)mm[NVW - 1]; m3 = (u32)(mm[NVW - 1] >> 32); }
+            m0 = (u32)rem[0]; m1 = (u32)(rem[0] >> 32);
+            if (NVW == 2) { m2 = (u32)rem[NVW - 1]; m3 = (u32)(rem[NVW - 1] >> 32); }
         }
         const int ta_ = tri2(a), tb_ = tri2(b);
         bool found = false;
@@ -529,6 +557,11 @@ __device__ void rips_sweep(int n, int E, int Ev, const u16* rank, int ns, Psi<W,
                 if (c == ycw) alive[c] &= (WT)~((WT)1 << ybit);
             __syncthreads();
             PROF_COUNT(10, 1);
+        }
+        // the chunk's edges join the adjacency rows
+        if (valid && tid < clen) {
+            atomicOr(reinterpret_cast<unsigned long long*>(&adj[2 * a + (b >> 6)]), 1ull << (b & 63));
+            atomicOr(reinterpret_cast<unsigned long long*>(&adj[2 * b + (a >> 6)]), 1ull << (a & 63));
         }
         __syncthreads();
         PROF_MARK(7);
