@@ -76,6 +76,9 @@ struct SweepShared {
     int k0, merges, status, clen;
 };
 
+typedef unsigned short pk_u16 __attribute__((ext_vector_type(2)));
+typedef short pk_i16 __attribute__((ext_vector_type(2)));
+
 template <int W, typename WT>
 struct __attribute__((aligned(sizeof(WT)))) Psi {
     WT w[W];            // W words of WT (u32: 32 classes per word, u64: 64)
@@ -306,20 +309,35 @@ __device__ void rips_sweep(int n, int E, int Ev, const u16* rank, int ns, Psi<W,
 #pragma unroll
         for (int w = 0; w < NVW; ++w) { M[w] = 0; M0[w] = 0; }
         if (valid) {
+            // packed 16-bit compare, 16 vertices per trip: max(rank[a][v], rank[b][v]) - r is negative
+            // exactly when both edges are older than r (ranks <= 0x7fff).  v_pk_max_u16 / v_pk_sub_i16 /
+            // v_pk_ashrrev_i16 handle two vertices per instruction.
             const u64* ra = reinterpret_cast<const u64*>(rank + a * ns);
             const u64* rb = reinterpret_cast<const u64*>(rank + b * ns);
-            const u64 H = 0x8000800080008000ull;
-            const u64 RR = (u64)r * 0x0001000100010001ull;
-            const int groups = (n + 3) >> 2;
-#pragma unroll 4
-            for (int g = 0; g < groups; ++g) {
-                const u64 xa = ra[g] | H, xb = rb[g] | H;
-                // per 16-bit field: (x|0x8000) - r never borrows; bit 15 clear  <=>  x < r
-                const u64 t = ~((xa - RR) | (xb - RR)) & H;
-                const u64 nib = ((t >> 15) & 1ull) | ((t >> 30) & 2ull) | ((t >> 45) & 4ull) | ((t >> 60) & 8ull);
-                if (NVW == 1) M[0] |= nib << (4 * g);
-                else M[(g >> 4) & (NVW - 1)] |= nib << (4 * (g & 15));
+            const pk_u16 rr2 = {(u16)r, (u16)r};
+            const int chunks = (n + 15) >> 4;
+            for (int c16 = 0; c16 < chunks; ++c16) {
+                u32 acc = 0;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const u64 xa = ra[4 * c16 + q], xb = rb[4 * c16 + q];   // may run past the row end: masked below
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const u32 wa = (u32)(xa >> (32 * h)), wb = (u32)(xb >> (32 * h));
+                        const pk_u16 mx = __builtin_elementwise_max(__builtin_bit_cast(pk_u16, wa), __builtin_bit_cast(pk_u16, wb));
+                        const pk_i16 df = __builtin_bit_cast(pk_i16, mx) - __builtin_bit_cast(pk_i16, rr2);
+                        const pk_i16 sg = df >> 15;
+                        const int k = 2 * q + h;                               // vertices 16*c16 + 2k, 2k+1
+                        acc |= __builtin_bit_cast(u32, sg) & ((1u << (2 * k)) | (1u << (2 * k + 17)));
+                    }
+                }
+                const u64 bits16 = (u64)((acc | (acc >> 16)) & 0xffffu);
+                if (NVW == 1) M[0] |= bits16 << (16 * c16);
+                else M[(c16 >> 2) & (NVW - 1)] |= bits16 << (16 * (c16 & 3));
             }
+            // drop the bits of padding vertices >= n
+            if (NVW == 1) { if (n < 64) M[0] &= (1ull << n) - 1ull; }
+            else { if (n < 128) M[NVW - 1] &= (n <= 64) ? 0ull : ((1ull << (n - 64)) - 1ull); if (n < 64) M[0] &= (1ull << n) - 1ull; }
 #pragma unroll
             for (int w = 0; w < NVW; ++w) M0[w] = adj[2 * a + w] & adj[2 * b + w];
         }
