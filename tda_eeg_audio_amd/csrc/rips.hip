@@ -655,15 +655,9 @@ struct KeyFromLds {
 };
 
 template <int NT, int NVW, int W, typename WT>
-__global__ void __launch_bounds__(NT)
-rips_dm_kernel(const double* __restrict__ dm, int n_win, int n, float thresh, int symmetrise, RipsLayout L,
-               RipsOut out, int retry_only)
+__device__ void rips_dm_window(unsigned char* smem, const int win, const double* __restrict__ dm, int n, float thresh,
+                               int symmetrise, const RipsLayout& L, const RipsOut& out)
 {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int win = blockIdx.x;
-    if (win >= n_win) return;
-    // retry pass with a wider class vector: only windows the previous pass flagged
-    if (retry_only && !(out.status[win] & TDA_WIN_CLASS_OVERFLOW)) return;
     const int tid = threadIdx.x;
     const int E = tri2(n);
     int npad = 2 * NT;
@@ -743,17 +737,29 @@ struct KeyFromPts {
     }
 };
 
-template <int NT, int W, typename WT>
+// Kernel shell shared by both flavours.  First pass: one workgroup per window.  Retry passes (wider
+// class vector) run a small grid that strides over the windows and only redoes the ones the previous
+// pass flagged, so a retry with nothing to do costs a few microseconds instead of n_win LDS-heavy
+// workgroup launches.
+template <int NT, int NVW, int W, typename WT>
 __global__ void __launch_bounds__(NT)
-rips_cloud_kernel(const double* __restrict__ src, const int* __restrict__ tau_or_npts, int n_win,
-                  int n_t_or_pcap, int dim, int subsample, int mode, int normalise, float thresh,
-                  RipsLayout L, int p_max, int* __restrict__ n_points, RipsOut out, int retry_only)
+rips_dm_kernel(const double* __restrict__ dm, int n_win, int n, float thresh, int symmetrise, RipsLayout L,
+               RipsOut out, int retry_only)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int win = blockIdx.x;
-    if (win >= n_win) return;
-    // retry pass with a wider class vector: only windows the previous pass flagged
-    if (retry_only && !(out.status[win] & TDA_WIN_CLASS_OVERFLOW)) return;
+    for (int win = blockIdx.x; win < n_win; win += gridDim.x) {
+        if (retry_only && !(out.status[win] & TDA_WIN_CLASS_OVERFLOW)) continue;   // workgroup-uniform
+        rips_dm_window<NT, NVW, W, WT>(smem, win, dm, n, thresh, symmetrise, L, out);
+        __syncthreads();
+    }
+}
+
+template <int NT, int W, typename WT>
+__device__ void rips_cloud_window(unsigned char* smem, const int win, const double* __restrict__ src,
+                                  const int* __restrict__ tau_or_npts, int n_t_or_pcap, int dim, int subsample,
+                                  int mode, int normalise, float thresh, const RipsLayout& L, int p_max,
+                                  int* __restrict__ n_points, const RipsOut& out)
+{
     const int tid = threadIdx.x;
     u64* S = reinterpret_cast<u64*>(smem);
     Psi<W, WT>* psi = reinterpret_cast<Psi<W, WT>*>(smem);
@@ -859,6 +865,21 @@ rips_cloud_kernel(const double* __restrict__ src, const int* __restrict__ tau_or
     if (tid == 0) { out.h0_cnt[win] = k0; out.h1_cnt[win] = k1; out.status[win] = st; }
 }
 
+template <int NT, int W, typename WT>
+__global__ void __launch_bounds__(NT)
+rips_cloud_kernel(const double* __restrict__ src, const int* __restrict__ tau_or_npts, int n_win,
+                  int n_t_or_pcap, int dim, int subsample, int mode, int normalise, float thresh,
+                  RipsLayout L, int p_max, int* __restrict__ n_points, RipsOut out, int retry_only)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    for (int win = blockIdx.x; win < n_win; win += gridDim.x) {
+        if (retry_only && !(out.status[win] & TDA_WIN_CLASS_OVERFLOW)) continue;   // workgroup-uniform
+        rips_cloud_window<NT, W, WT>(smem, win, src, tau_or_npts, n_t_or_pcap, dim, subsample, mode, normalise,
+                                     thresh, L, p_max, n_points, out);
+        __syncthreads();
+    }
+}
+
 // ---------------------------------------------------------------------------------
 // H1 rows -> ripser's order (descending birth; ties: descending death, then emission order)
 // ---------------------------------------------------------------------------------
@@ -935,7 +956,8 @@ static tda_status launch_dm_t(tda_ctx* ctx, const double* dm, int n_win, int n, 
     if (L.total > 48 * 1024)
         TDA_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, L.total));
-    hipLaunchKernelGGL(kern, dim3(n_win), dim3(NT), L.total, st, dm, n_win, n, thresh, symmetrise, L, out,
+    const int grid = retry_only ? (n_win < 64 ? n_win : 64) : n_win;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(NT), L.total, st, dm, n_win, n, thresh, symmetrise, L, out,
                        retry_only);
     TDA_HIP(ctx, hipGetLastError());
     return TDA_OK;
@@ -994,7 +1016,8 @@ static tda_status launch_cloud_t(tda_ctx* ctx, const double* src, const int* aux
     if (L.total > 48 * 1024)
         TDA_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, L.total));
-    hipLaunchKernelGGL(kern, dim3(n_win), dim3(NT), L.total, st, src, aux, n_win, n_t_or_pcap, dim, subsample, mode,
+    const int grid = retry_only ? (n_win < 64 ? n_win : 64) : n_win;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(NT), L.total, st, src, aux, n_win, n_t_or_pcap, dim, subsample, mode,
                        normalise, thresh, L, p_max, n_points, out, retry_only);
     TDA_HIP(ctx, hipGetLastError());
     return TDA_OK;
