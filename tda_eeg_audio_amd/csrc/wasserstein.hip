@@ -164,6 +164,54 @@ wasserstein_kernel(const double* __restrict__ dgm_a, const int* __restrict__ cnt
     WPROF(0, WCLK() - wt0); wt0 = WCLK();
     WPROF(4, 1); WPROF(5, R); WPROF(6, Cn);
 
+    // ---- 1-D fast path ------------------------------------------------------------------
+    // If every point of both diagrams has the same birth (two H0 diagrams: births 0) the points lie
+    // on a line, the ground cost is |d_i - d_j| and, for any fixed sets of matched points, the sorted
+    // (non-crossing) pairing is optimal.  The optimum over partial matchings is then the edit-distance
+    // style recurrence  F[i][j] = min(F[i-1][j], F[i][j-1], F[i-1][j-1] + g_ij)  over death-sorted
+    // diagrams - an anti-diagonal wavefront with one row per lane, R + C - 1 steps instead of
+    // hundreds of Dijkstra steps.  Same gains g_ij as the general solver (so the same rounding of
+    // C_ij); the value differs from the assignment optimum by at most the rounding noise of C.
+    {
+        bool ok = R <= 64;
+        const double b0 = rb[0];
+        for (int i0 = 0; i0 < R; i0 += 64) {
+            const int i = i0 + lane;
+            ok = ok && !__ballot(i < R && (rb[i] != b0 || (i + 1 < R && rd[i + 1] < rd[i])));
+        }
+        for (int j0 = 0; j0 < Cn; j0 += 64) {
+            const int j = j0 + lane;
+            ok = ok && !__ballot(j < Cn && (cb[j] != b0 || (j + 1 < Cn && cd[j + 1] < cd[j])));
+        }
+        if (ok) {
+            double cur = 0.0, nb1 = 0.0, nb2 = 0.0;      // own F, neighbour row's F one / two steps ago
+            const int nsteps1d = R + Cn - 1;
+            for (int t = 0; t < nsteps1d; ++t) {
+                const int j0 = t - lane;
+                // neighbour (row lane-1) value of the previous step; row 0 sees the zero boundary
+                const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(cur), 0x138, 0xF, 0xF, false);
+                const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(cur), 0x138, 0xF, 0xF, false);
+                nb2 = nb1;
+                nb1 = __hiloint2double(hi, lo);
+                if (lane < R && j0 >= 0 && j0 < Cn) {
+                    const double g = use_matrix ? G[lane * Cn + j0] : gain(lane, j0);
+                    const double up = nb1;                          // F[row][j0+1] of the row above
+                    const double dg = (j0 == 0 ? 0.0 : nb2) + g;    // F[row above][j0] + g
+                    double m = up < cur ? up : cur;                 // cur still holds F[row+1][j0] (left)
+                    m = dg < m ? dg : m;
+                    cur = m;
+                }
+            }
+            const double fbest = uni_f64(cur, R - 1);
+            double part = 0.0;
+            for (int i = lane; i < R; i += 64) part += rs[i];
+            for (int j = lane; j < Cn; j += 64) part += ct[j];
+            const double total1d = wave_sum_f64(part) + fbest;
+            if (lane == 0) { out[pr] = total1d; status[pr] = 0; }
+            return;
+        }
+    }
+
     // per-lane state, all in registers: column j = lane + 64*c holds v, minv, way, used, prow;
     // row i = lane + 64*c holds its dual u and the "row is in the alternating tree" flag.
     // The Dijkstra step therefore touches LDS only for the cost row (one read per column slot).

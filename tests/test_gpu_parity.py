@@ -333,6 +333,35 @@ def test_wasserstein_vs_persim_restatement_and_bruteforce(ctx):
         assert abs(out[i] - brute.wasserstein_bruteforce(As[i], Bs[i])) < 1e-9
 
 
+def test_wasserstein_equal_birth_fast_path(ctx):
+    """Two diagrams whose points all share one birth (H0 vs H0) take the 1-D wavefront path: compare
+    with the full assignment (persim restatement on scipy's solver), incl. coincident and duplicated
+    deaths, and check that unsorted input (general solver) gives the same value."""
+    rng = np.random.default_rng(21)
+    As, Bs = [], []
+    for k in range(120):
+        m, n = int(rng.integers(1, 60)), int(rng.integers(1, 125))
+        a = np.sort(rng.random(m).astype(np.float32).astype(np.float64)) * (1.5 if k % 3 else 0.3)
+        b = np.sort(rng.random(n).astype(np.float32).astype(np.float64)) * (0.4 if k % 2 else 1.5)
+        if k % 5 == 0:
+            b[: min(m, n) // 2] = a[: min(m, n) // 2][: len(b[: min(m, n) // 2])]     # exact coincidences
+            b = np.sort(b)
+        if k % 7 == 0:
+            a[1:] = np.where(rng.random(m - 1) < 0.3, a[:-1], a[1:]); a = np.sort(a)  # duplicates
+        birth = 0.0 if k % 4 else 0.125
+        As.append(np.stack([np.full(m, birth), birth + a], 1)); Bs.append(np.stack([np.full(n, birth), birth + b], 1))
+    ra, ca = engine.pack_diagrams(As, cap=64); rb, cb = engine.pack_diagrams(Bs, cap=128)
+    out, st = engine.wasserstein_batch(ra, ca, rb, cb, ctx=ctx, want_status=True)
+    ref = np.array([brute.wasserstein_persim(a, b) for a, b in zip(As, Bs)])
+    assert not st.any() and np.abs(out - ref).max() < 1e-9, np.abs(out - ref).max()
+    # shuffled rows -> not sorted -> general solver; same optimum
+    As2 = [a[rng.permutation(len(a))] for a in As]
+    Bs2 = [b[rng.permutation(len(b))] for b in Bs]
+    ra2, ca2 = engine.pack_diagrams(As2, cap=64); rb2, cb2 = engine.pack_diagrams(Bs2, cap=128)
+    out2 = engine.wasserstein_batch(ra2, ca2, rb2, cb2, ctx=ctx)
+    assert np.abs(out2 - ref).max() < 1e-9 and np.abs(out2 - out).max() < 1e-9
+
+
 def test_wasserstein_infinite_rows_ignored_and_index_pairs(ctx):
     A = np.array([[0.0, 0.5], [0.0, np.inf], [0.1, 0.7]])
     B = np.array([[0.0, np.inf]])
