@@ -213,6 +213,31 @@ __device__ __forceinline__ bool scan_word(u32& mw, const int vbase, const Psi<W,
     return false;
 }
 
+// Effective threshold = min(thresh, enclosing radius).  At the enclosing radius
+// r_enc = min_v max_u d(v,u) some vertex is adjacent to every other one, the complex is a cone and
+// stays one: H0 is connected, every H1 class is dead and every later edge is killed at once by the
+// apex with zero persistence.  Edges longer than r_enc therefore cannot contribute a diagram row
+// (ripser applies the same cut when no threshold is given); dropping them shortens the sweep.
+// vmax[v] (u32 sortable keys, LDS) must hold max_u key(v,u) on entry.  Returns the number of edges
+// whose key is <= the effective threshold (workgroup-uniform) .
+template <int NT>
+__device__ int count_effective_edges(const u64* S, int E, int n, u32 tkey, const u32* vmax, int* red)
+{
+    const int tid = threadIdx.x;
+    u32 renc = 0xffffffffu;
+    for (int v = 0; v < n; ++v) { const u32 m = vmax[v]; renc = m < renc ? m : renc; }
+    const u32 teff = renc < tkey ? renc : tkey;
+    int ev = 0;
+    for (int e = tid; e < E; e += NT) ev += ((u32)(S[e] >> 16) <= teff) ? 1 : 0;
+    if (tid == 0) *red = 0;
+    __syncthreads();
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) ev += __shfl_xor(ev, off, 64);
+    if ((tid & 63) == 0) atomicAdd(red, ev);
+    __syncthreads();
+    return *red;
+}
+
 struct RipsOut {
     double* h0; int h0_cap; int* h0_cnt;
     double* h1; int h1_cap; int* h1_cnt;
@@ -673,7 +698,9 @@ __device__ void rips_dm_window(unsigned char* smem, const int win, const double*
     const double* D = dm + (size_t)win * n * n;
     const u32 tkey = f32_sortable(thresh);
     // P0. keys: utils.py:137-139 then ripser's float32 cast
-    int ev = 0;
+    u32* vmax = reinterpret_cast<u32*>(misc + MISC_COMP);
+    if (tid < 128) vmax[tid] = 0u;
+    __syncthreads();
     for (int e = tid; e < E; e += NT) {
         const int a = edge_row(e), b = e - tri2(a);
         double v;
@@ -685,16 +712,12 @@ __device__ void rips_dm_window(unsigned char* smem, const int win, const double*
         }
         const u32 sk = f32_sortable((float)v);
         S[e] = ((u64)sk << 16) | (u64)((a << 8) | b);
-        ev += (sk <= tkey) ? 1 : 0;
+        atomicMax(&vmax[a], sk);
+        atomicMax(&vmax[b], sk);
     }
     for (int e = E + tid; e < npad; e += NT) S[e] = ~0ull;
-    if (tid == 0) *red = 0;
     __syncthreads();
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) ev += __shfl_xor(ev, off, 64);
-    if ((tid & 63) == 0) atomicAdd(red, ev);
-    __syncthreads();
-    const int Ev = *red;
+    const int Ev = count_effective_edges<NT>(S, E, n, tkey, vmax, red);
     PROF_MARK(0);
     bitonic_sort_lds<NT>(S, npad);
     PROF_MARK(1);
@@ -833,21 +856,19 @@ __device__ void rips_cloud_window(unsigned char* smem, const int win, const doub
     while (npad < E) npad <<= 1;
     const u32 tkey = f32_sortable(thresh);
     KeyFromPts kf{pts, dim};
-    int ev = 0;
+    u32* vmax = reinterpret_cast<u32*>(misc + MISC_COMP);
+    if (tid < 128) vmax[tid] = 0u;
+    __syncthreads();
     for (int e = tid; e < E; e += NT) {
         const int a = edge_row(e), b = e - tri2(a);
         const u32 sk = f32_sortable(kf(0, a, b));
         S[e] = ((u64)sk << 16) | (u64)((a << 8) | b);
-        ev += (sk <= tkey) ? 1 : 0;
+        atomicMax(&vmax[a], sk);
+        atomicMax(&vmax[b], sk);
     }
     for (int e = E + tid; e < npad; e += NT) S[e] = ~0ull;
-    if (tid == 0) *red = 0;
     __syncthreads();
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) ev += __shfl_xor(ev, off, 64);
-    if ((tid & 63) == 0) atomicAdd(red, ev);
-    __syncthreads();
-    const int Ev = *red;
+    const int Ev = count_effective_edges<NT>(S, E, P, tkey, vmax, red);
     PROF_MARK(0);
     bitonic_sort_lds<NT>(S, npad);
     PROF_MARK(1);
