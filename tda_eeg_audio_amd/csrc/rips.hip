@@ -5,34 +5,38 @@
 // scripts/utils.py:131 (incl. the Takens embedding utils.py:107-116 and the min-max
 // normalisation utils.py:127-130 in front of it).
 //
-// One window per workgroup of NT = 256 threads (4 waves); everything between the input read
-// and the diagram rows lives in LDS / registers.  The algorithm is NOT ripser's (heap columns
-// do not map to a GPU); it is an edge-parallel formulation of the same persistence pairing:
+// One window per workgroup (256 threads for distance matrices, 512 for point clouds); everything
+// between the input read and the diagram rows lives in LDS / registers.  The algorithm is NOT
+// ripser's (heap columns do not map to a GPU); it is an edge-parallel formulation of the same
+// persistence pairing:
 //
-//  P0  all n(n-1)/2 float32 edge lengths are packed as (sortable key << 16 | a << 8 | b);
-//  P1  bitonic sort in LDS (whole workgroup);
-//  P2  ord[r] = (a,b) of the r-th edge, rank[a][b] = r (0x7fff for absent edges, d > thresh);
+//  P0  all n(n-1)/2 float32 edge lengths are packed as (sortable key << 16 | a << 8 | b); edges
+//      longer than min(thresh, enclosing radius) are dropped (they cannot contribute a row);
+//  P1  bitonic sort in LDS (whole workgroup, two butterfly stages per pass);
+//  P2  rank[a][b] = r for the r-th edge (0x7fff for absent edges) -- adjacency "at time r" becomes
+//      the comparison rank < r; no rank -> edge table is kept;
 //  P3  sweep over the filtration in chunks of NT consecutive edges, ONE EDGE PER LANE:
-//      a. common-neighbour mask  M_r = { v : rank[a][v] < r and rank[b][v] < r }  (4 vertices per
-//         64-bit LDS read, borrow-free packed 16-bit compare) -- no sequential adjacency state;
-//      b. edges with M_r = 0 are the only candidates for negative (spanning-forest) edges: a
-//         short sequential union-find over just those decides   merge -> H0 death at |e|
-//                                                               else  -> a new H1 class is born;
-//      c. every other edge is killed at once by its triangle with the lowest apex v*:
-//         psi[e] = psi[a,v*] ^ psi[b,v*], where psi[edge] in LDS is the class of the cycle
-//         "edge + forest path" as a bit vector over the currently alive H1 classes
-//         (dependencies inside the chunk are resolved in a few rounds);
-//      d. each lane scans its other triangles (a,b,v), v in M_r: boundary class
-//         psi[e]^psi[a,v]^psi[b,v].  The earliest non-zero one in the chunk kills the YOUNGEST
-//         class in it (elder rule): that class is substituted out of the whole psi table, the
-//         pair (birth, |e|) is emitted, and the scan resumes.  This happens exactly once per
-//         H1 class that ever dies (tens per window), so the table pass is rare.
+//      a. common-neighbour mask  M_r = { v : rank[a][v] < r and rank[b][v] < r }  (packed 16-bit
+//         compares, 16 vertices per trip) -- no sequential adjacency state;
+//      b. edges with M_r = 0 are the only candidates for negative (spanning-forest) edges: wave 0
+//         walks them in rank order with the component labels in registers and decides
+//                                      merge -> H0 death at |e|   /   else -> a new H1 class is born;
+//      c. every other edge is killed at once by a triangle (a,b,v*), v* preferably a common
+//         neighbour that predates the chunk:  psi[e] = psi[a,v*] ^ psi[b,v*], where psi[edge] in LDS
+//         is the class of the cycle "edge + forest path" as a bit vector over the alive H1 classes;
+//      d. LINK ARGUMENT: common neighbours v, v' that are adjacent span a tetrahedron with (a,b)
+//         whose other two faces entered earlier, so triangles (a,b,v) and (a,b,v') carry the same
+//         boundary class.  Only common neighbours outside the connected component of v* in the link
+//         (closure over adjacency bit rows) are tested: psi[e]^psi[a,v]^psi[b,v].  The earliest
+//         non-zero one in the chunk kills the YOUNGEST class in it (elder rule): that class is
+//         substituted out of the whole psi table and the pair (birth, |e|) is emitted.  This happens
+//         exactly once per H1 class that ever dies (tens per window).
 //      The multiset of (birth,death) pairs equals that of any persistence algorithm on the
 //      same filtration; tie order inside equal diameters does not change it.
 //  P4  rows are written as float64 (float32-exact) pairs: H0 ascending death then the essential
 //      rows; H1 rows are ordered by a second tiny kernel (descending birth).
 //
-// LDS per workgroup: 31 KB (n = 47, 128 classes) .. 112 KB (n = 124 point cloud).
+// LDS per workgroup: 36 KB (n = 47, 128 classes) .. 80 KB (n = 124 point cloud, 32-bit classes).
 // No MFMA: this is irregular integer work; the roofline that binds it is LDS latency/issue.
 #include "common.h"
 
