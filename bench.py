@@ -51,6 +51,9 @@ def main():
     ap.add_argument("--band", default="beta")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--share-gpu", action="store_true",
+                    help="rehearsal only: every rank uses cuda:0 and the all-gather goes through gloo "
+                         "(exercises the N>1 code path on a one-GPU box; numbers are meaningless)")
     args = ap.parse_args()
 
     import torch
@@ -58,7 +61,11 @@ def main():
     from tda_eeg_audio_amd import _lib, pipeline, synth
     from tda_eeg_audio_amd import dist as tdist
 
-    rank, world, local = tdist.init_from_env()
+    if args.share_gpu:
+        os.environ["LOCAL_RANK_REAL"] = os.environ.get("LOCAL_RANK", "0")
+    rank, world, local = tdist.init_from_env(backend="gloo" if args.share_gpu else None)
+    if args.share_gpu:
+        local = 0
     assert world == args.gpus or world == 1, f"WORLD_SIZE={world} but --gpus {args.gpus}"
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
@@ -107,7 +114,7 @@ def main():
         dist.barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        t = torch.tensor([dt], dtype=torch.float64, device="cpu" if args.share_gpu else device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     for evs in ev_log:

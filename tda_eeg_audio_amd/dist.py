@@ -45,7 +45,13 @@ def all_gather_rows(local_rows, my_recs, shards, n_total, group=None):
     send = torch.zeros((pad, k), dtype=local_rows.dtype, device=local_rows.device)
     send[: local_rows.shape[0]] = local_rows
     recv = torch.empty((world * pad, k), dtype=local_rows.dtype, device=local_rows.device)
-    dist.all_gather_into_tensor(recv, send, group=group)
+    if dist.get_backend(group) == "gloo" and send.is_cuda:
+        # rehearsal on a shared GPU: gloo collectives are staged through host memory
+        r_h = torch.empty(recv.shape, dtype=recv.dtype)
+        dist.all_gather_into_tensor(r_h, send.cpu(), group=group)
+        recv.copy_(r_h)
+    else:
+        dist.all_gather_into_tensor(recv, send, group=group)
     out = torch.empty((n_total, k), dtype=local_rows.dtype, device=local_rows.device)
     for r, s in enumerate(shards):
         if len(s):
