@@ -187,3 +187,123 @@ def process_recording_arrays(audio_band_windows, eeg_dists_by_band):
             "audio_h1_features": fa, "eeg_h1_features": fe,
         }
     return out
+
+
+# --------------------------------------------------------------------------------------
+# whole-corpus feature matrix (scripts/tda_eeg_classification_v2.py:445-606, 670-688)
+# --------------------------------------------------------------------------------------
+def compute_min_windows_per_band(graphs_dirs, freq_bands=BANDS):
+    """v2:445-474 -- global per-band minimum window count (np.load with mmap: headers only)."""
+    min_windows = {band: np.inf for band in freq_bands}
+    for graphs_dir in graphs_dirs:
+        graphs_dir = Path(graphs_dir)
+        if not graphs_dir.exists():
+            continue
+        for file_dir in [d for d in graphs_dir.iterdir() if d.is_dir()]:
+            for band in freq_bands:
+                dist_file = file_dir / f"{band}_distances.npy"
+                if not dist_file.exists():
+                    continue
+                try:
+                    n_windows = np.load(dist_file, mmap_mode="r").shape[0]
+                    if n_windows > 0:
+                        min_windows[band] = min(min_windows[band], n_windows)
+                except Exception:
+                    continue
+    return {b: (0 if v == np.inf else int(v)) for b, v in min_windows.items()}
+
+
+def _entries(graphs_dir_slow, graphs_dir_fast, batch_start=0, batch_end=None):
+    """v2:532-541 -- sorted slow recordings (label 0) then sorted fast ones (label 1), sliced."""
+    slow = sorted([d for d in Path(graphs_dir_slow).iterdir() if d.is_dir()])
+    fast = sorted([d for d in Path(graphs_dir_fast).iterdir() if d.is_dir()])
+    entries = [(d, 0) for d in slow] + [(d, 1) for d in fast]
+    total = len(entries)
+    if batch_end is None or batch_end < 0:
+        batch_end = total
+    return entries[max(0, batch_start):min(batch_end, total)], total
+
+
+def create_dataset(graphs_dir_slow, graphs_dir_fast, freq_bands=BANDS, max_dim=1, max_edge_length=MAX_EDGE_LENGTH,
+                   equalize_windows=True, window_sampling="random", max_windows_per_band="min", random_state=42,
+                   batch_start=0, batch_end=None, rank=0, world_size=1, gather=None):
+    """v2:499-606.  Returns (X, y, subjects, feature_names, filenames, metadata) with the reference's
+    row order.  All recordings of this call go through ONE Rips launch (+ features + aggregation).
+
+    world_size > 1: recordings are dealt to ranks by dist.shard_recordings (descending window
+    count), every rank computes its rows and `gather(local_rows, my_recs, shards, n_total)`
+    (dist.all_gather_rows) assembles the full X on every rank -- this replaces the reference's
+    BATCH_START/BATCH_END partial files and their merge (v2:55-60, 608-638)."""
+    if equalize_windows and max_windows_per_band == "min":
+        max_windows_per_band = compute_min_windows_per_band([graphs_dir_slow, graphs_dir_fast], freq_bands)
+    elif not equalize_windows:
+        max_windows_per_band = None
+    entries, _ = _entries(graphs_dir_slow, graphs_dir_fast, batch_start, batch_end)
+    n_rec = len(entries)
+    names = feature_names(freq_bands)
+    # window counts decide the sharding (mmap: headers only)
+    n_win_rec = np.zeros(n_rec, dtype=np.int64)
+    for i, (d, _) in enumerate(entries):
+        for band in freq_bands:
+            f = d / f"{band}_distances.npy"
+            if f.exists():
+                n_win_rec[i] += np.load(f, mmap_mode="r").shape[0]
+    if world_size > 1:
+        from . import dist as tdist
+        shards = tdist.shard_recordings(n_win_rec, world_size)
+        mine = shards[rank]
+    else:
+        shards, mine = None, np.arange(n_rec)
+    groups, where, metadata = [], [], [None] * n_rec
+    for i in mine:
+        file_dir, label = entries[i]
+        md = {"n_windows": {}, "n_windows_used": {}, "validation_issues": [], "window_sampling": window_sampling,
+              "max_windows_per_band": max_windows_per_band}
+        for bi, band in enumerate(freq_bands):
+            dist_file = file_dir / f"{band}_distances.npy"
+            if not dist_file.exists():
+                md["n_windows"][band] = 0
+                continue
+            dms = np.load(dist_file)
+            n_windows = dms.shape[0]
+            md["n_windows"][band] = n_windows
+            if n_windows == 0:
+                continue
+            if max_windows_per_band is None:
+                use = np.arange(n_windows)
+            else:
+                max_n = max_windows_per_band.get(band, n_windows) if isinstance(max_windows_per_band, dict) \
+                    else int(max_windows_per_band)
+                max_n = min(max_n, n_windows)
+                use = select_windows_md5(file_dir.name, band, n_windows, max_n, random_state) \
+                    if window_sampling == "random" else np.arange(max_n)
+            md["n_windows_used"][band] = len(use)
+            groups.append(dms[use]); where.append((i, bi))
+        md["n_windows_total"] = int(sum(md["n_windows"].values()))
+        md["n_windows_used_total"] = int(sum(md["n_windows_used"].values()))
+        md["filename"] = file_dir.name; md["subject"] = file_dir.name.split("_")[0]; md["label"] = label
+        metadata[i] = md
+    X = np.full((n_rec, 44 * len(freq_bands)), np.nan)
+    if groups:
+        agg = features_from_distances(groups, max_edge_length)
+        for g, (i, bi) in enumerate(where):
+            X[i, 44 * bi:44 * (bi + 1)] = agg[g]
+    if world_size > 1:
+        import torch
+        local = torch.from_numpy(X[mine])
+        X = gather(local, mine, shards, n_rec).numpy()
+    y = np.array([lab for _, lab in entries])
+    filenames = [d.name for d, _ in entries]
+    subjects = np.array([f.split("_")[0] for f in filenames])
+    return X, y, subjects, names, filenames, [m for m in metadata if m is not None]
+
+
+def save_dataset(features_dir, X, y, subjects, names, filenames):
+    """v2:670-682 -- features/X.npy, y.npy, subjects.npy, feature_names.txt, filenames.txt."""
+    features_dir = Path(features_dir)
+    features_dir.mkdir(exist_ok=True, parents=True)
+    np.save(features_dir / "X.npy", X)
+    np.save(features_dir / "y.npy", y)
+    np.save(features_dir / "subjects.npy", subjects)
+    (features_dir / "feature_names.txt").write_text("".join(f"{n}\n" for n in names))
+    (features_dir / "filenames.txt").write_text("".join(f"{n}\n" for n in filenames))

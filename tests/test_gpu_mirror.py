@@ -97,3 +97,42 @@ def test_drivers_process_file_features_and_cross_wasserstein(ctx, tmp_path):
     out = drivers.process_recording_arrays({"delta": synth.audio_windows(40, "delta", seed=2)}, {"delta": dists["delta"]})
     assert out["delta"]["n_windows"] == 15 and out["delta"]["tau"] >= 1
     assert np.isfinite(out["delta"]["wasserstein_h0"]) and out["delta"]["eeg_h1_features"].shape == (15, 11)
+
+
+def test_create_dataset_on_graphs_tree(ctx, tmp_path):
+    """v2:499-606 on a small synthetic graphs/ tree: row order, 220 columns, window equalisation by
+    the global per-band minimum with md5-seeded sampling; values against the oracle."""
+    bands = ["delta", "theta", "alpha", "beta", "gamma"]
+    recs = {"slow": [("bb01_ut01", 44), ("bb02_ut03", 41)], "fast": [("bb01_ut05", 40), ("bb03_ut02", 43)]}
+    store = {}
+    for cond, lst in recs.items():
+        for name, nwin in lst:
+            d = tmp_path / "graphs" / cond / name
+            d.mkdir(parents=True)
+            for bi, band in enumerate(bands):
+                W = synth.eeg_windows(nwin + bi, seed=hash((name, band)) % 10000)
+                dm = port.corr_dist_batch(W)[1]
+                np.save(d / f"{band}_distances.npy", dm)
+                store[(name, band)] = dm
+    X, y, subjects, names, filenames, meta = drivers.create_dataset(tmp_path / "graphs" / "slow", tmp_path / "graphs" / "fast")
+    assert X.shape == (4, 220) and list(y) == [0, 0, 1, 1]
+    assert filenames == ["bb01_ut01", "bb02_ut03", "bb01_ut05", "bb03_ut02"] and list(subjects) == ["bb01", "bb02", "bb01", "bb03"]
+    assert names == drivers.feature_names() and np.isfinite(X).all()
+    mins = drivers.compute_min_windows_per_band([tmp_path / "graphs" / "slow", tmp_path / "graphs" / "fast"])
+    assert mins == {b: 40 + i for i, b in enumerate(bands)}
+    assert meta[0]["n_windows_used"] == mins and meta[0]["subject"] == "bb01"
+    # one recording-band against the oracle
+    name, band, bi = "bb03_ut02", "alpha", 2
+    use = drivers.select_windows_md5(name, band, store[(name, band)].shape[0], mins[band])
+    f0 = np.array([port.features(port.rips_dm(store[(name, band)][i])[0]) for i in use])
+    f1 = np.array([port.features(port.rips_dm(store[(name, band)][i])[1]) for i in use])
+    row = X[3, 44 * bi:44 * (bi + 1)]
+    exp = np.stack([f0.mean(0), f0.std(0), f1.mean(0), f1.std(0)], 1).ravel()
+    assert np.allclose(row, exp, rtol=1e-12, atol=1e-15)
+    # batch slicing (BATCH_START/BATCH_END semantics, v2:537-541)
+    Xb, yb, _, _, fb, _ = drivers.create_dataset(tmp_path / "graphs" / "slow", tmp_path / "graphs" / "fast",
+                                                 batch_start=1, batch_end=3)
+    assert fb == filenames[1:3] and np.array_equal(Xb, X[1:3])
+    drivers.save_dataset(tmp_path / "features", X, y, subjects, names, filenames)
+    assert np.array_equal(np.load(tmp_path / "features" / "X.npy"), X)
+    assert (tmp_path / "features" / "feature_names.txt").read_text().split() == names
