@@ -35,8 +35,9 @@ ALG_BYTES = {
     "rips_audio": 250 * 8 + 4 + 1500,                 # ~3.5 KB/window
     "wasserstein_h0": 2700 + 8,                       # <= 2.7 KB/pair
     "wasserstein_h1": 2700 + 8,
-    "features": 3 * (1100 + 88),
-    "aggregate": 2 * 22 * 8,
+    "features_eeg": 2 * (1100 + 88) + 2 * 22 * 8,
+    "features_audio": 1100 + 88,
+    "reduce": 2 * 8,
 }
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 

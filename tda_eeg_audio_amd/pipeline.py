@@ -70,35 +70,34 @@ def run_step(eeg_win, audio_win, ws, ctx=None, max_lag=125, timers=None):
     with torch.cuda.stream(side):
         stage("corr_dist", lambda: engine.corr_dist_dev(eeg_win, ws.dist, None, ctx=ctx))
         stage("rips_eeg", lambda: engine.rips_dm_dev(ws.dist, ws.eeg, ctx=ctx))
+
+        # everything that depends on the EEG diagrams only also stays on the side stream
+        def eeg_feats():
+            engine.features_dev(ws.eeg.h0, ws.eeg.c0, ws.fe0, ctx=ctx)
+            engine.features_dev(ws.eeg.h1, ws.eeg.c1, ws.fe1, ctx=ctx)
+            ws.result[:, 4:] = engine.aggregate_dev(ws.fe0, ws.fe1, ws.seg_off, ctx=ctx)
+        stage("features_eeg", eeg_feats)
     # tau from the first selected window of each recording-band (cmp:83), broadcast to its windows
     first = audio_win.index_select(0, ws.first_idx)
     stage("tau", lambda: engine.tau_dev(first, max_lag, ws.tau_seg, ctx=ctx))
     tau_w = ws.tau_seg.index_select(0, ws.rec_id)
     stage("rips_audio", lambda: engine.takens_rips_dev(audio_win, tau_w, ws.aud, ctx=ctx))
+    stage("features_audio", lambda: engine.features_dev(ws.aud.h1, ws.aud.c1, ws.fa1, ctx=ctx))
     main.wait_stream(side)
     stage("wasserstein_h0", lambda: engine.wasserstein_dev(ws.eeg.h0, ws.eeg.c0, ws.aud.h0, ws.aud.c0,
                                                            out_t=ws.w0, status_t=ws.ws0, ctx=ctx))
     stage("wasserstein_h1", lambda: engine.wasserstein_dev(ws.eeg.h1, ws.eeg.c1, ws.aud.h1, ws.aud.c1,
                                                            out_t=ws.w1, status_t=ws.ws1, ctx=ctx))
 
-    def feats():
-        engine.features_dev(ws.eeg.h0, ws.eeg.c0, ws.fe0, ctx=ctx)
-        engine.features_dev(ws.eeg.h1, ws.eeg.c1, ws.fe1, ctx=ctx)
-        engine.features_dev(ws.aud.h1, ws.aud.c1, ws.fa1, ctx=ctx)
-    stage("features", feats)
-
-    # per recording-band reductions (strided column views are not contiguous: reduce into temporaries)
+    # per recording-band reductions (cmp:117-118)
     def agg():
-        m0 = engine.segment_nanmean_dev(ws.w0, ws.seg_off, ctx=ctx)
-        m1 = engine.segment_nanmean_dev(ws.w1, ws.seg_off, ctx=ctx)
-        a = engine.aggregate_dev(ws.fe0, ws.fe1, ws.seg_off, ctx=ctx)
-        ws.result[:, 0] = m0
-        ws.result[:, 1] = m1
+        ws.result[:, 0] = engine.segment_nanmean_dev(ws.w0, ws.seg_off, ctx=ctx)
+        ws.result[:, 1] = engine.segment_nanmean_dev(ws.w1, ws.seg_off, ctx=ctx)
         ws.result[:, 2] = ws.tau_seg.to(torch.float64)
         ws.result[:, 3] = ws.n_win_seg
-        ws.result[:, 4:] = a
-    stage("aggregate", agg)
+    stage("reduce", agg)
     return ws.result
 
 
-STAGES = ["corr_dist", "rips_eeg", "tau", "rips_audio", "wasserstein_h0", "wasserstein_h1", "features", "aggregate"]
+STAGES = ["corr_dist", "rips_eeg", "features_eeg", "tau", "rips_audio", "features_audio", "wasserstein_h0",
+          "wasserstein_h1", "reduce"]
