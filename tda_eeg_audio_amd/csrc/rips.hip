@@ -155,7 +155,7 @@ __device__ void bitonic_sort_lds(u64* S, int npad)
         int j = k >> 1;
         while (j >= 2) {
             const int jh = j >> 1;
-#pragma unroll 2
+#pragma unroll 4
             for (int t = tid; t < (npad >> 2); t += NT) {
                 const int b = ((t & ~(jh - 1)) << 2) | (t & (jh - 1));
                 const bool up = (b & k) == 0;
@@ -386,8 +386,9 @@ __device__ void rips_sweep(int n, int E, int Ev, const u16* rank, int ns, Psi<W,
         // wave 0 alone walks the candidates in rank order (the other waves would only replay the
         // same scalar work and fight for issue slots); LDS accesses of one wave are in order
         if (wave == 0) {
+            const u64 candv = cand[lane & (NT / 64 - 1)];     // all ballots in one LDS read
             for (int g = 0; g < NT / 64 && !status && clen == NT; ++g) {
-                u64 cb = cand[g];
+                u64 cb = rl64(candv, g);
                 if (!cb) continue;
                 // this group's edges and lengths into registers: the walk below is LDS-free
                 const u32 pkv = ordc[64 * g + lane];

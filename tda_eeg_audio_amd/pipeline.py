@@ -44,6 +44,8 @@ class Workspace:
         self.result = torch.empty((self.n_seg, RESULT_COLS), **f64)
         self.n_win_seg = torch.from_numpy(np.diff(seg_off).astype(np.float64)).to(device)
         self.side_stream = torch.cuda.Stream(device=device)
+        import os
+        self.overlap = os.environ.get("TDA_OVERLAP", "1") != "0"     # EEG chain on a side stream
 
 
 def run_step(eeg_win, audio_win, ws, ctx=None, max_lag=125, timers=None):
@@ -65,8 +67,9 @@ def run_step(eeg_win, audio_win, ws, ctx=None, max_lag=125, timers=None):
     # the Wasserstein step: the EEG kernels (31 KB LDS per workgroup) run on a side stream and
     # co-reside on the CUs with the audio kernel (113 KB), filling its idle issue slots.
     main = torch.cuda.current_stream()
-    side = ws.side_stream
-    side.wait_stream(main)
+    side = ws.side_stream if ws.overlap else main
+    if ws.overlap:
+        side.wait_stream(main)
     with torch.cuda.stream(side):
         stage("corr_dist", lambda: engine.corr_dist_dev(eeg_win, ws.dist, None, ctx=ctx))
         stage("rips_eeg", lambda: engine.rips_dm_dev(ws.dist, ws.eeg, ctx=ctx))
@@ -83,7 +86,8 @@ def run_step(eeg_win, audio_win, ws, ctx=None, max_lag=125, timers=None):
     tau_w = ws.tau_seg.index_select(0, ws.rec_id)
     stage("rips_audio", lambda: engine.takens_rips_dev(audio_win, tau_w, ws.aud, ctx=ctx))
     stage("features_audio", lambda: engine.features_dev(ws.aud.h1, ws.aud.c1, ws.fa1, ctx=ctx))
-    main.wait_stream(side)
+    if ws.overlap:
+        main.wait_stream(side)
     stage("wasserstein_h0", lambda: engine.wasserstein_dev(ws.eeg.h0, ws.eeg.c0, ws.aud.h0, ws.aud.c0,
                                                            out_t=ws.w0, status_t=ws.ws0, ctx=ctx))
     stage("wasserstein_h1", lambda: engine.wasserstein_dev(ws.eeg.h1, ws.eeg.c1, ws.aud.h1, ws.aud.c1,
