@@ -81,6 +81,17 @@ tda_status tda_corr_dist_batch_dev(tda_ctx* ctx, const double* win, int n_win, i
 tda_status tda_corr_dist_batch(tda_ctx* ctx, const double* win, int n_win, int n_ch, int n_t,
                                double* dist, double* corr);
 
+/* Sliding windows fused in: create_sliding_windows (notebooks/1_preprocesamiento.ipynb:314-381;
+ * window w = samples [w*step, w*step+win_len), n_win = (n_samples-win_len)/step+1) followed by the
+ * per-window corr->dist above, reading the overlapping windows straight from ONE band-passed
+ * recording sig (n_ch, n_samples) float64 -- the (n_win, n_ch, win_len) stack (4x the bytes at 75 %
+ * overlap) is never materialised.  dist/corr: (n_win, n_ch, n_ch); n_win (out, nullable).      */
+tda_status tda_corr_dist_sliding_dev(tda_ctx* ctx, const double* sig, int n_ch, int n_samples,
+                                     int win_len, int step, double* dist, double* corr, int* n_win,
+                                     void* stream);
+tda_status tda_corr_dist_sliding(tda_ctx* ctx, const double* sig, int n_ch, int n_samples,
+                                 int win_len, int step, double* dist, double* corr, int* n_win);
+
 /* correlation_to_distance (nb2:100-122) alone, on stored correlation matrices.
  * method: 0 "euclidean" (the only one the reference calls, nb2:227,304,312), 1 "abs",
  *         2 "standard", 3 "sqrt" (nb2:109-116).  corr, dist: (n_win, n, n) float64.          */

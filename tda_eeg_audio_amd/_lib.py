@@ -35,6 +35,8 @@ SYMBOLS = {
     "tda_set_class_words": (_I, [c_vp, _I, _I]),
     "tda_corr_dist_batch_dev": (_I, [c_vp, c_vp, _I, _I, _I, c_vp, c_vp, c_vp]),
     "tda_corr_dist_batch": (_I, [c_vp, c_vp, _I, _I, _I, c_vp, c_vp]),
+    "tda_corr_dist_sliding_dev": (_I, [c_vp, c_vp, _I, _I, _I, _I, c_vp, c_vp, c_vp, c_vp]),
+    "tda_corr_dist_sliding": (_I, [c_vp, c_vp, _I, _I, _I, _I, c_vp, c_vp, c_vp]),
     "tda_corr_to_dist_batch_dev": (_I, [c_vp, c_vp, _I, _I, _I, c_vp, c_vp]),
     "tda_corr_to_dist_batch": (_I, [c_vp, c_vp, _I, _I, _I, c_vp]),
     "tda_rips_dm_batch_dev": (_I, [c_vp, c_vp, _I, _I, _D, _I, c_vp, _I, c_vp, c_vp, _I, c_vp, c_vp, c_vp]),

@@ -72,6 +72,14 @@ tda_status tda_corr_dist_batch_dev(tda_ctx* ctx, const double* win, int n_win, i
     return launch_corr_dist(ctx, win, n_win, n_ch, n_t, dist, corr, (hipStream_t)stream);
 }
 
+tda_status tda_corr_dist_sliding_dev(tda_ctx* ctx, const double* sig, int n_ch, int n_samples, int win_len, int step,
+                                     double* dist, double* corr, int* n_win, void* stream)
+{
+    CHECK_CTX(ctx); CHECK_PTR(ctx, sig); CHECK_PTR(ctx, dist);
+    CHECK_NONNEG(ctx, n_samples);
+    return launch_corr_dist_sliding(ctx, sig, n_ch, n_samples, win_len, step, dist, corr, n_win, (hipStream_t)stream);
+}
+
 tda_status tda_corr_to_dist_batch_dev(tda_ctx* ctx, const double* corr, int n_win, int n, int method, double* dist,
                                       void* stream)
 {
@@ -216,6 +224,25 @@ tda_status tda_corr_dist_batch(tda_ctx* ctx, const double* win, int n_win, int n
     if (corr) s.add((void**)&d_corr, nullptr, corr, nw * n_ch * n_ch * 8);
     RET_IF(s.upload());
     RET_IF(tda_corr_dist_batch_dev(ctx, d_win, n_win, n_ch, n_t, d_dist, d_corr, nullptr));
+    return s.download();
+}
+
+tda_status tda_corr_dist_sliding(tda_ctx* ctx, const double* sig, int n_ch, int n_samples, int win_len, int step,
+                                 double* dist, double* corr, int* n_win)
+{
+    CHECK_CTX(ctx); CHECK_PTR(ctx, sig); CHECK_PTR(ctx, dist); CHECK_NONNEG(ctx, n_samples);
+    if (win_len < 2 || step < 1 || n_ch < 1) TDA_FAIL(ctx, TDA_ERR_INVALID, "bad window geometry");
+    const int nw = n_samples >= win_len ? (n_samples - win_len) / step + 1 : 0;
+    if (n_win) *n_win = nw;
+    if (nw == 0) return TDA_OK;
+    TDA_HIP(ctx, hipSetDevice(ctx->device));
+    Stage s(ctx);
+    double *d_sig, *d_dist, *d_corr = nullptr;
+    s.add((void**)&d_sig, sig, nullptr, (size_t)n_ch * n_samples * 8);
+    s.add((void**)&d_dist, nullptr, dist, (size_t)nw * n_ch * n_ch * 8);
+    if (corr) s.add((void**)&d_corr, nullptr, corr, (size_t)nw * n_ch * n_ch * 8);
+    RET_IF(s.upload());
+    RET_IF(tda_corr_dist_sliding_dev(ctx, d_sig, n_ch, n_samples, win_len, step, d_dist, d_corr, nullptr, nullptr));
     return s.download();
 }
 

@@ -112,6 +112,7 @@ __device__ __forceinline__ float sortable_f32(u32 s)
 
 // launch-side entry points implemented in the .hip files
 tda_status launch_corr_dist(tda_ctx*, const double*, int, int, int, double*, double*, hipStream_t);
+tda_status launch_corr_dist_sliding(tda_ctx*, const double*, int, int, int, int, double*, double*, int*, hipStream_t);
 tda_status launch_corr_to_dist(tda_ctx*, const double*, int, int, int, double*, hipStream_t);
 tda_status launch_rips_dm(tda_ctx*, const double*, int, int, double, int, double*, int, int*, double*, int, int*,
                           int*, hipStream_t);

@@ -17,7 +17,7 @@
 #define CD_MAXCH 64
 
 __global__ void __launch_bounds__(256)
-corr_dist_kernel(const double* __restrict__ win, int n_win, int n_ch, int n_t,
+corr_dist_kernel(const double* __restrict__ win, int n_win, int n_ch, int n_t, long long win_stride, int ld,
                  double* __restrict__ dist, double* __restrict__ corr)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -28,7 +28,11 @@ corr_dist_kernel(const double* __restrict__ win, int n_win, int n_ch, int n_t,
     const int w = blockIdx.x;
     if (w >= n_win) return;
     const int tid = threadIdx.x;
-    const double* X = win + (size_t)w * n_ch * n_t;
+    // window w = n_ch rows of n_t samples, row stride ld, starting win_stride elements after window w-1:
+    //   stacked windows (preprocessed/<band>.npy): win_stride = n_ch*n_t, ld = n_t
+    //   sliding windows over one band-passed recording (n_ch, L): win_stride = step, ld = L -- the 75 %
+    //   overlap (nb1:338-341) is then served by L2 instead of being materialised 4x in HBM
+    const double* X = win + (size_t)w * (size_t)win_stride;
 
     // 3x3 tile owned by this thread: (ti <= tj) over a T x T tile grid
     const int T = (n_ch + 2) / 3;
@@ -44,7 +48,7 @@ corr_dist_kernel(const double* __restrict__ win, int n_win, int n_ch, int n_t,
         const int tc = (n_t - c0) < CD_TC ? (n_t - c0) : CD_TC;
         for (int idx = tid; idx < n_ch * tc; idx += 256) {
             const int ch = idx / tc, t = idx - ch * tc;
-            tile[ch * CD_TCP + t] = X[(size_t)ch * n_t + c0 + t];
+            tile[ch * CD_TCP + t] = X[(size_t)ch * ld + c0 + t];
         }
         __syncthreads();
         if (tid < n_ch)
@@ -64,7 +68,7 @@ corr_dist_kernel(const double* __restrict__ win, int n_win, int n_ch, int n_t,
         const int tc = (n_t - c0) < CD_TC ? (n_t - c0) : CD_TC;
         for (int idx = tid; idx < n_ch * tc; idx += 256) {
             const int ch = idx / tc, t = idx - ch * tc;
-            tile[ch * CD_TCP + t] = X[(size_t)ch * n_t + c0 + t] - mean[ch];
+            tile[ch * CD_TCP + t] = X[(size_t)ch * ld + c0 + t] - mean[ch];
         }
         __syncthreads();
         if (has_tile) {
@@ -160,7 +164,25 @@ tda_status launch_corr_dist(tda_ctx* ctx, const double* win, int n_win, int n_ch
     if (n_ch < 1 || n_ch > CD_MAXCH) TDA_FAIL(ctx, TDA_ERR_UNSUPPORTED, "n_ch must be in [1,64]");
     if (n_t < 2) TDA_FAIL(ctx, TDA_ERR_INVALID, "n_t must be >= 2");
     const size_t lds = sizeof(double) * ((size_t)n_ch * CD_TCP + (size_t)n_ch * n_ch + 2 * (size_t)n_ch);
-    hipLaunchKernelGGL(corr_dist_kernel, dim3(n_win), dim3(256), lds, st, win, n_win, n_ch, n_t, dist, corr);
+    hipLaunchKernelGGL(corr_dist_kernel, dim3(n_win), dim3(256), lds, st, win, n_win, n_ch, n_t,
+                       (long long)n_ch * n_t, n_t, dist, corr);
+    TDA_HIP(ctx, hipGetLastError());
+    return TDA_OK;
+}
+
+// sliding windows over a (n_ch, n_samples) band-passed recording: create_sliding_windows
+// (notebooks/1_preprocesamiento.ipynb:314-381) fused with the per-window corr->dist loop (nb2:198-207)
+tda_status launch_corr_dist_sliding(tda_ctx* ctx, const double* sig, int n_ch, int n_samples, int win_len, int step,
+                                    double* dist, double* corr, int* n_win_out, hipStream_t st)
+{
+    if (n_ch < 1 || n_ch > CD_MAXCH) TDA_FAIL(ctx, TDA_ERR_UNSUPPORTED, "n_ch must be in [1,64]");
+    if (win_len < 2 || step < 1) TDA_FAIL(ctx, TDA_ERR_INVALID, "win_len must be >= 2 and step >= 1");
+    const int n_win = n_samples >= win_len ? (n_samples - win_len) / step + 1 : 0;   // nb1:341
+    if (n_win_out) *n_win_out = n_win;
+    if (n_win == 0) return TDA_OK;
+    const size_t lds = sizeof(double) * ((size_t)n_ch * CD_TCP + (size_t)n_ch * n_ch + 2 * (size_t)n_ch);
+    hipLaunchKernelGGL(corr_dist_kernel, dim3(n_win), dim3(256), lds, st, sig, n_win, n_ch, win_len, (long long)step,
+                       n_samples, dist, corr);
     TDA_HIP(ctx, hipGetLastError());
     return TDA_OK;
 }

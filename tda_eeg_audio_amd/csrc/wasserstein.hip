@@ -81,6 +81,7 @@ wasserstein_kernel(const double* __restrict__ dgm_a, const int* __restrict__ cnt
     if (pr >= n_pairs) return;
     const int lane = lane_id();
     unsigned long long wt0 = WCLK();
+    (void)wt0;
     // LDS: row points (b,d,s) | col points (b,d,t) | u[rows] | cost matrix (optional)
     double* rb = reinterpret_cast<double*>(smem);
     double* rd = rb + max_rows;
@@ -224,6 +225,7 @@ wasserstein_kernel(const double* __restrict__ dgm_a, const int* __restrict__ cnt
     const double INF = __longlong_as_double(0x7ff0000000000000ll);
     bool failed = false;
     int nsteps = 0;
+    (void)nsteps;
     // ---- row-reduction start: u_i = min_j g_ij, v = 0 is dual feasible; every row whose arg-min
     // column is not claimed by a lower row is assigned at once (tight pair), the rest augment ----
     bool rowdone[CW];

@@ -36,6 +36,32 @@ def corr_dist_batch(windows, want_corr=True, ctx=None):
     return (corr, dist) if want_corr else dist
 
 
+def corr_dist_sliding(signal, win_len=250, step=62, want_corr=False, ctx=None):
+    """(n_ch, n_samples) band-passed recording -> distance matrices of its sliding windows
+    (nb1:314-381 + nb2:198-207 fused)."""
+    ctx = ctx or get_ctx()
+    s = f64(signal)
+    n_ch, n_s = s.shape
+    n_win = (n_s - win_len) // step + 1 if n_s >= win_len else 0
+    dist = np.empty((n_win, n_ch, n_ch))
+    corr = np.empty((n_win, n_ch, n_ch)) if want_corr else None
+    ctx.check(ctx.lib.tda_corr_dist_sliding(ctx.h, ptr(s), n_ch, n_s, win_len, step, ptr(dist), ptr(corr), None))
+    return (corr, dist) if want_corr else dist
+
+
+def corr_dist_sliding_dev(sig_t, win_len=250, step=62, dist_t=None, corr_t=None, ctx=None):
+    import torch
+    ctx = ctx or get_ctx()
+    assert sig_t.is_cuda and sig_t.dtype == torch.float64 and sig_t.is_contiguous()
+    n_ch, n_s = sig_t.shape
+    n_win = (n_s - win_len) // step + 1 if n_s >= win_len else 0
+    if dist_t is None:
+        dist_t = torch.empty((n_win, n_ch, n_ch), dtype=torch.float64, device=sig_t.device)
+    ctx.check(ctx.lib.tda_corr_dist_sliding_dev(ctx.h, _tp(sig_t), n_ch, n_s, win_len, step, _tp(dist_t), _tp(corr_t),
+                                                None, _stream()))
+    return dist_t
+
+
 DIST_METHODS = {"euclidean": 0, "abs": 1, "standard": 2, "sqrt": 3}     # nb2:107-116
 
 

@@ -43,6 +43,21 @@ def test_corr_dist_vs_reference_golden(ctx, golden):
     assert np.array_equal(dist.astype(np.float32), golden["cd_dist"].astype(np.float32))
 
 
+def test_corr_dist_sliding_equals_stacked_windows(ctx):
+    """Sliding windows read in place from the recording == create_sliding_windows + per-window loop."""
+    rng = np.random.default_rng(4)
+    for n_s in (4606, 2663, 250, 249, 311):
+        sig = rng.standard_normal((47, n_s)) + 0.3 * rng.standard_normal((1, n_s))
+        corr, dist = engine.corr_dist_sliding(sig, 250, 62, want_corr=True, ctx=ctx)
+        n_win = (n_s - 250) // 62 + 1 if n_s >= 250 else 0
+        assert dist.shape == (n_win, 47, 47)
+        if n_win:
+            stack = np.stack([sig[:, i * 62:i * 62 + 250] for i in range(n_win)])
+            oc, od = port.corr_dist_batch(stack)
+            assert np.array_equal(dist, od) and np.array_equal(corr, oc)
+    assert (4606 - 250) // 62 + 1 == 71          # results/preprocessing_metadata.csv:2
+
+
 def test_corr_dist_other_shapes(ctx):
     rng = np.random.default_rng(3)
     for n_ch, n_t in [(2, 5), (8, 64), (47, 500), (64, 100), (33, 51)]:
