@@ -148,6 +148,28 @@ tda_status tda_cloud_rips_batch(tda_ctx* ctx, const double* pc, const int* n_pts
                                 double* h0, int h0_cap, int* h0_cnt,
                                 double* h1, int h1_cap, int* h1_cnt, int* status);
 
+/* ---- zero-phase IIR filtering (front ends) ----------------------------
+ * tda_sosfiltfilt replaces scipy.signal.sosfiltfilt(sos, x) as apply_bandpass_filter calls it per
+ * EEG channel (notebooks/1_preprocesamiento.ipynb:236-263); tda_filtfilt replaces
+ * scipy.signal.filtfilt(b, a, s) of bandpass_filter (scripts/utils.py:66-74).  Same algorithm as
+ * scipy (odd extension by `edge`, forward from zi*x[0], backward from zi*y[-1], trim), same
+ * operation order: bit-identical float64 results.  Filter design stays on the host:
+ *   sos (n_sections,6) from scipy.signal.butter(..., output="sos"), zi (n_sections,2) from sosfilt_zi,
+ *   edge = 3*(2*n_sections+1 - min(#b2==0, #a2==0));   b, a (ntaps), zi (ntaps-1) from lfilter_zi,
+ *   edge = 3*ntaps.
+ * x, y: (n_sig, n_samples) float64; work (device, *_dev only): (n_sig, n_samples + 2*edge).
+ * sos / zi / b / a are HOST pointers in both forms (they travel as kernel arguments).           */
+tda_status tda_sosfiltfilt_dev(tda_ctx* ctx, const double* x, int n_sig, int n_samples, const double* sos,
+                               const double* zi, int n_sections, int edge, double* y, double* work,
+                               void* stream);
+tda_status tda_sosfiltfilt(tda_ctx* ctx, const double* x, int n_sig, int n_samples, const double* sos,
+                           const double* zi, int n_sections, int edge, double* y);
+tda_status tda_filtfilt_dev(tda_ctx* ctx, const double* x, int n_sig, int n_samples, const double* b,
+                            const double* a, const double* zi, int ntaps, int edge, double* y, double* work,
+                            void* stream);
+tda_status tda_filtfilt(tda_ctx* ctx, const double* x, int n_sig, int n_samples, const double* b,
+                        const double* a, const double* zi, int ntaps, int edge, double* y);
+
 /* ---- delay from the first zero crossing of the autocorrelation ---------------
  * replaces compute_tau (scripts/utils.py:92-104). max_lag < 0 = None (len/4).         */
 tda_status tda_tau_batch_dev(tda_ctx* ctx, const double* win, int n_win, int n_t, int max_lag,

@@ -48,6 +48,10 @@ SYMBOLS = {
     "tda_cloud_rips_batch_dev": (_I, [c_vp, c_vp, c_vp, _I, _I, _I, _I, _D, c_vp, _I, c_vp, c_vp, _I, c_vp,
                                       c_vp, c_vp]),
     "tda_cloud_rips_batch": (_I, [c_vp, c_vp, c_vp, _I, _I, _I, _I, _D, c_vp, _I, c_vp, c_vp, _I, c_vp, c_vp]),
+    "tda_sosfiltfilt_dev": (_I, [c_vp, c_vp, _I, _I, c_vp, c_vp, _I, _I, c_vp, c_vp, c_vp]),
+    "tda_sosfiltfilt": (_I, [c_vp, c_vp, _I, _I, c_vp, c_vp, _I, _I, c_vp]),
+    "tda_filtfilt_dev": (_I, [c_vp, c_vp, _I, _I, c_vp, c_vp, c_vp, _I, _I, c_vp, c_vp, c_vp]),
+    "tda_filtfilt": (_I, [c_vp, c_vp, _I, _I, c_vp, c_vp, c_vp, _I, _I, c_vp]),
     "tda_tau_batch_dev": (_I, [c_vp, c_vp, _I, _I, _I, c_vp, c_vp]),
     "tda_tau_batch": (_I, [c_vp, c_vp, _I, _I, _I, c_vp]),
     "tda_features_batch_dev": (_I, [c_vp, c_vp, c_vp, _I, _I, c_vp, c_vp]),

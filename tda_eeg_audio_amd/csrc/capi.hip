@@ -127,6 +127,24 @@ tda_status tda_cloud_rips_batch_dev(tda_ctx* ctx, const double* pc, const int* n
                              h1_cap, h1_cnt, nullptr, status, (hipStream_t)stream);
 }
 
+tda_status tda_sosfiltfilt_dev(tda_ctx* ctx, const double* x, int n_sig, int n_samples, const double* sos,
+                               const double* zi, int n_sections, int edge, double* y, double* work, void* stream)
+{
+    CHECK_CTX(ctx); CHECK_NONNEG(ctx, n_sig);
+    if (n_sig) { CHECK_PTR(ctx, x); CHECK_PTR(ctx, y); CHECK_PTR(ctx, work); }
+    CHECK_PTR(ctx, sos); CHECK_PTR(ctx, zi);
+    return launch_sosfiltfilt(ctx, x, n_sig, n_samples, sos, zi, n_sections, edge, y, work, (hipStream_t)stream);
+}
+
+tda_status tda_filtfilt_dev(tda_ctx* ctx, const double* x, int n_sig, int n_samples, const double* b, const double* a,
+                            const double* zi, int ntaps, int edge, double* y, double* work, void* stream)
+{
+    CHECK_CTX(ctx); CHECK_NONNEG(ctx, n_sig);
+    if (n_sig) { CHECK_PTR(ctx, x); CHECK_PTR(ctx, y); CHECK_PTR(ctx, work); }
+    CHECK_PTR(ctx, b); CHECK_PTR(ctx, a); CHECK_PTR(ctx, zi);
+    return launch_filtfilt(ctx, x, n_sig, n_samples, b, a, zi, ntaps, edge, y, work, (hipStream_t)stream);
+}
+
 tda_status tda_tau_batch_dev(tda_ctx* ctx, const double* win, int n_win, int n_t, int max_lag, int* tau, void* stream)
 {
     CHECK_CTX(ctx); CHECK_NONNEG(ctx, n_win);
@@ -336,6 +354,42 @@ tda_status tda_cloud_rips_batch(tda_ctx* ctx, const double* pc, const int* n_pts
     RET_IF(s.upload());
     RET_IF(tda_cloud_rips_batch_dev(ctx, d_pc, d_n, n_win, p_cap, dim, normalise, thresh, d_h0, h0_cap, d_c0, d_h1,
                                     h1_cap, d_c1, d_st, nullptr));
+    return s.download();
+}
+
+tda_status tda_sosfiltfilt(tda_ctx* ctx, const double* x, int n_sig, int n_samples, const double* sos, const double* zi,
+                           int n_sections, int edge, double* y)
+{
+    CHECK_CTX(ctx); CHECK_NONNEG(ctx, n_sig);
+    if (n_sig == 0) return TDA_OK;
+    CHECK_PTR(ctx, x); CHECK_PTR(ctx, y); CHECK_PTR(ctx, sos); CHECK_PTR(ctx, zi);
+    if (n_samples < 1 || edge < 0) TDA_FAIL(ctx, TDA_ERR_INVALID, "bad sizes");
+    TDA_HIP(ctx, hipSetDevice(ctx->device));
+    Stage s(ctx);
+    double *d_x, *d_y, *d_w;
+    s.add((void**)&d_x, x, nullptr, (size_t)n_sig * n_samples * 8);
+    s.add((void**)&d_y, nullptr, y, (size_t)n_sig * n_samples * 8);
+    s.add((void**)&d_w, nullptr, nullptr, (size_t)n_sig * (n_samples + 2 * edge) * 8);
+    RET_IF(s.upload());
+    RET_IF(tda_sosfiltfilt_dev(ctx, d_x, n_sig, n_samples, sos, zi, n_sections, edge, d_y, d_w, nullptr));
+    return s.download();
+}
+
+tda_status tda_filtfilt(tda_ctx* ctx, const double* x, int n_sig, int n_samples, const double* b, const double* a,
+                        const double* zi, int ntaps, int edge, double* y)
+{
+    CHECK_CTX(ctx); CHECK_NONNEG(ctx, n_sig);
+    if (n_sig == 0) return TDA_OK;
+    CHECK_PTR(ctx, x); CHECK_PTR(ctx, y); CHECK_PTR(ctx, b); CHECK_PTR(ctx, a); CHECK_PTR(ctx, zi);
+    if (n_samples < 1 || edge < 0) TDA_FAIL(ctx, TDA_ERR_INVALID, "bad sizes");
+    TDA_HIP(ctx, hipSetDevice(ctx->device));
+    Stage s(ctx);
+    double *d_x, *d_y, *d_w;
+    s.add((void**)&d_x, x, nullptr, (size_t)n_sig * n_samples * 8);
+    s.add((void**)&d_y, nullptr, y, (size_t)n_sig * n_samples * 8);
+    s.add((void**)&d_w, nullptr, nullptr, (size_t)n_sig * (n_samples + 2 * edge) * 8);
+    RET_IF(s.upload());
+    RET_IF(tda_filtfilt_dev(ctx, d_x, n_sig, n_samples, b, a, zi, ntaps, edge, d_y, d_w, nullptr));
     return s.download();
 }
 

@@ -119,6 +119,10 @@ tda_status launch_rips_dm(tda_ctx*, const double*, int, int, double, int, double
 tda_status launch_rips_cloud(tda_ctx*, const double* win_or_pc, const int* tau_or_npts, int n_win, int n_t_or_pcap,
                              int dim, int subsample, int mode, int normalise, double thresh, double*, int, int*,
                              double*, int, int*, int* n_points, int*, hipStream_t);
+tda_status launch_sosfiltfilt(tda_ctx*, const double*, int, int, const double*, const double*, int, int, double*, double*,
+                              hipStream_t);
+tda_status launch_filtfilt(tda_ctx*, const double*, int, int, const double*, const double*, const double*, int, int, double*,
+                           double*, hipStream_t);
 tda_status launch_tau(tda_ctx*, const double*, int, int, int, int*, hipStream_t);
 tda_status launch_features(tda_ctx*, const double*, const int*, int, int, double*, hipStream_t);
 tda_status launch_aggregate(tda_ctx*, const double*, const double*, const int*, int, double*, hipStream_t);

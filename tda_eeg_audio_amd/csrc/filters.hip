@@ -1,0 +1,171 @@
+// filters.hip -- zero-phase IIR filtering of many signals at once (SURVEY.md section 8f "next" rows 2-3).
+//
+//   sosfiltfilt_kernel  replaces scipy.signal.sosfiltfilt(sos, x) as called per channel by
+//                       apply_bandpass_filter (notebooks/1_preprocesamiento.ipynb:236-263, sos from
+//                       design_bandpass_filter nb1:209-233): the EEG band-pass in front of the windows.
+//   filtfilt_kernel     replaces scipy.signal.filtfilt(b, a, s) of bandpass_filter
+//                       (scripts/utils.py:66-74): the per-band filter of the audio envelope.
+//
+// Both follow scipy's algorithm exactly: odd extension by `edge` samples at both ends, forward
+// pass started from zi * ext[0], backward pass over the reversed output started from zi * y[-1],
+// trim.  The recursions are direct form II transposed with scipy's operation order (no fused
+// multiply-add; the file is built with -ffp-contract=off), so results are bit-identical to scipy on
+// the same float64 input.  Filter DESIGN (butter -> sos / ba, sosfilt_zi / lfilter_zi, edge) is
+// host-side preparation done with scipy itself.
+//
+// The recursion is sequential in time, so parallelism comes from the signals: one lane per signal,
+// 64 signals per workgroup.  Samples move through a 64 x 64 LDS tile so that HBM is read and written
+// in rows (coalesced) while each lane walks its own row of the tile.
+#include "common.h"
+
+#define FT 64            // tile: FT signals x FT samples
+#define FTP (FT + 1)     // padded row (doubles): lane-per-row walks are bank-conflict free
+#define F_MAX_SEC 8      // second-order sections
+#define F_MAX_TAPS 17    // len(b) = len(a) of the ba form
+
+struct SosParams {
+    double c[F_MAX_SEC][6];   // b0 b1 b2 a0 a1 a2 per section
+    double zi[F_MAX_SEC][2];
+    int n_sec;
+};
+struct BaParams {
+    double b[F_MAX_TAPS], a[F_MAX_TAPS];   // already divided by a[0]
+    double zi[F_MAX_TAPS];                 // lfilter_zi, length ntaps-1
+    int ntaps;
+};
+
+// odd extension (scipy.signal._arraytools.odd_ext): index i of the padded signal, N = L + 2*edge
+__device__ __forceinline__ double odd_ext_at(const double* __restrict__ x, int L, int edge, int i)
+{
+    if (i < edge) return 2.0 * x[0] - x[edge - i];
+    if (i < edge + L) return x[i - edge];
+    const int k = i - (edge + L);
+    return 2.0 * x[L - 1] - x[L - 2 - k];
+}
+
+// FILTER::step(state, x) -> y ; FILTER::init(state, params, x0)
+struct SosFilter {
+    double z[F_MAX_SEC][2];
+    __device__ __forceinline__ void init(const SosParams& p, double x0)
+    {
+#pragma unroll
+        for (int s = 0; s < F_MAX_SEC; ++s) { z[s][0] = p.zi[s][0] * x0; z[s][1] = p.zi[s][1] * x0; }
+    }
+    __device__ __forceinline__ double step(const SosParams& p, double x_cur)
+    {
+        // scipy/signal/_sosfilt.pyx: x_new = b0*x + z0; z0 = (b1*x - a1*x_new + z1); z1 = (b2*x - a2*x_new)
+#pragma unroll
+        for (int s = 0; s < F_MAX_SEC; ++s) {
+            if (s >= p.n_sec) break;                       // uniform: state stays in registers
+            const double x_new = p.c[s][0] * x_cur + z[s][0];
+            z[s][0] = (p.c[s][1] * x_cur - p.c[s][4] * x_new) + z[s][1];
+            z[s][1] = p.c[s][2] * x_cur - p.c[s][5] * x_new;
+            x_cur = x_new;
+        }
+        return x_cur;
+    }
+};
+
+struct BaFilter {
+    double z[F_MAX_TAPS];
+    __device__ __forceinline__ void init(const BaParams& p, double x0)
+    {
+#pragma unroll
+        for (int k = 0; k < F_MAX_TAPS - 1; ++k) z[k] = p.zi[k] * x0;
+    }
+    __device__ __forceinline__ double step(const BaParams& p, double xn)
+    {
+        // scipy/signal/_lfilter.c.in (DOUBLE_filt): yn = Z[0] + b0*xn; Z[n] = Z[n+1] + xn*b[n+1] - yn*a[n+1]
+        // b, a, zi are zero beyond ntaps, so running all F_MAX_TAPS-1 delays is the same recursion:
+        // the delay at ntaps-2 reads z[ntaps-1] = 0 and delays above stay 0 (their +0.0 never changes a sum
+        // except the sign of an exact zero, which no later operation can observe in y)
+        const double yn = z[0] + p.b[0] * xn;
+#pragma unroll
+        for (int n = 0; n < F_MAX_TAPS - 2; ++n) z[n] = (z[n + 1] + xn * p.b[n + 1]) - yn * p.a[n + 1];
+        z[F_MAX_TAPS - 2] = xn * p.b[F_MAX_TAPS - 1] - yn * p.a[F_MAX_TAPS - 1];
+        return yn;
+    }
+};
+
+template <class FILT, class PARAMS>
+__global__ void __launch_bounds__(FT)
+zero_phase_kernel(const double* __restrict__ x, int n_sig, int L, int edge, PARAMS p, double* __restrict__ y,
+                  double* __restrict__ work)
+{
+    __shared__ double tile[FT * FTP];
+    const int lane = threadIdx.x;
+    const int s0 = blockIdx.x * FT;
+    const int sig = s0 + lane;
+    const int N = L + 2 * edge;
+    const bool live = sig < n_sig;
+    FILT f;
+    // ---- forward over the odd extension, output to work (n_sig, N) ----
+    for (int c0 = 0; c0 < N; c0 += FT) {
+        const int cn = (N - c0) < FT ? (N - c0) : FT;
+        // load rows s0..s0+63, samples c0..c0+cn: lane = sample (coalesced along the row)
+        for (int r = 0; r < FT; ++r)
+            if (s0 + r < n_sig && lane < cn) tile[r * FTP + lane] = odd_ext_at(x + (size_t)(s0 + r) * L, L, edge, c0 + lane);
+        __syncthreads();
+        if (live) {
+            if (c0 == 0) f.init(p, tile[lane * FTP]);
+            for (int t = 0; t < cn; ++t) tile[lane * FTP + t] = f.step(p, tile[lane * FTP + t]);
+        }
+        __syncthreads();
+        for (int r = 0; r < FT; ++r)
+            if (s0 + r < n_sig && lane < cn) work[(size_t)(s0 + r) * N + c0 + lane] = tile[r * FTP + lane];
+        __syncthreads();
+    }
+    // ---- backward over work, trimmed result to y (n_sig, L) ----
+    for (int c1 = N; c1 > 0; c1 -= FT) {
+        const int c0 = c1 - FT > 0 ? c1 - FT : 0;
+        const int cn = c1 - c0;
+        for (int r = 0; r < FT; ++r)
+            if (s0 + r < n_sig && lane < cn) tile[r * FTP + lane] = work[(size_t)(s0 + r) * N + c0 + lane];
+        __syncthreads();
+        if (live) {
+            if (c1 == N) f.init(p, tile[lane * FTP + cn - 1]);       // zi * y[-1]
+            for (int t = cn - 1; t >= 0; --t) tile[lane * FTP + t] = f.step(p, tile[lane * FTP + t]);
+        }
+        __syncthreads();
+        for (int r = 0; r < FT; ++r) {
+            const int i = c0 + lane;                                  // index in the padded signal
+            if (s0 + r < n_sig && lane < cn && i >= edge && i < edge + L) y[(size_t)(s0 + r) * L + i - edge] = tile[r * FTP + lane];
+        }
+        __syncthreads();
+    }
+}
+
+tda_status launch_sosfiltfilt(tda_ctx* ctx, const double* x, int n_sig, int L, const double* sos, const double* zi,
+                              int n_sec, int edge, double* y, double* work, hipStream_t st)
+{
+    if (n_sig == 0) return TDA_OK;
+    if (n_sec < 1 || n_sec > F_MAX_SEC) TDA_FAIL(ctx, TDA_ERR_UNSUPPORTED, "n_sections must be in [1,8]");
+    if (edge < 0 || L <= edge) TDA_FAIL(ctx, TDA_ERR_INVALID, "signal length must exceed the pad length");   // scipy raises too
+    SosParams p = {};
+    p.n_sec = n_sec;
+    for (int s = 0; s < n_sec; ++s) {
+        for (int k = 0; k < 6; ++k) p.c[s][k] = sos[s * 6 + k];
+        p.zi[s][0] = zi[s * 2]; p.zi[s][1] = zi[s * 2 + 1];
+    }
+    hipLaunchKernelGGL((zero_phase_kernel<SosFilter, SosParams>), dim3((n_sig + FT - 1) / FT), dim3(FT), 0, st, x, n_sig,
+                       L, edge, p, y, work);
+    TDA_HIP(ctx, hipGetLastError());
+    return TDA_OK;
+}
+
+tda_status launch_filtfilt(tda_ctx* ctx, const double* x, int n_sig, int L, const double* b, const double* a,
+                           const double* zi, int ntaps, int edge, double* y, double* work, hipStream_t st)
+{
+    if (n_sig == 0) return TDA_OK;
+    if (ntaps < 2 || ntaps > F_MAX_TAPS) TDA_FAIL(ctx, TDA_ERR_UNSUPPORTED, "len(b)=len(a) must be in [2,17]");
+    if (edge < 0 || L <= edge) TDA_FAIL(ctx, TDA_ERR_INVALID, "signal length must exceed the pad length");
+    BaParams p;
+    p.ntaps = ntaps;
+    const double a0 = a[0];
+    for (int k = 0; k < F_MAX_TAPS; ++k) { p.b[k] = k < ntaps ? b[k] / a0 : 0.0; p.a[k] = k < ntaps ? a[k] / a0 : 0.0; }
+    for (int k = 0; k < F_MAX_TAPS; ++k) p.zi[k] = k < ntaps - 1 ? zi[k] : 0.0;
+    hipLaunchKernelGGL((zero_phase_kernel<BaFilter, BaParams>), dim3((n_sig + FT - 1) / FT), dim3(FT), 0, st, x, n_sig,
+                       L, edge, p, y, work);
+    TDA_HIP(ctx, hipGetLastError());
+    return TDA_OK;
+}

@@ -1,0 +1,137 @@
+"""
+preprocess.py -- front ends of the hot path ("next" rows 2-3), same names as
+the reference:
+
+  design_bandpass_filter, apply_bandpass_filter, create_sliding_windows
+        notebooks/1_preprocesamiento.ipynb:209-263, 314-381  (EEG: zero-phase Butterworth per channel)
+  bandpass_filter
+        scripts/utils.py:66-74                               (audio envelope: filtfilt per band)
+  eeg_to_distances
+        preprocess_file (nb1:388-494) + process_file_graphs (nb2:158-218) fused: raw EEG (47, L) ->
+        per band: band-pass on the GPU -> correlation/distance of the sliding windows read in place;
+        neither the filtered windows stack (n_win, 47, 250) nor its 4x overlap ever exist.
+
+Filter DESIGN (scipy.signal.butter, sosfilt_zi / lfilter_zi, pad length) is host-side preparation
+done with scipy, exactly as the reference does; the recursions run in csrc/filters.hip and are
+bit-identical to scipy.signal.sosfiltfilt / filtfilt.
+"""
+import ctypes as C
+
+import numpy as np
+from scipy import signal
+
+from . import engine
+from ._lib import f64, get_ctx, ptr
+
+FREQ_BANDS = {"delta": (0.5, 4), "theta": (4, 8), "alpha": (8, 13), "beta": (13, 30), "gamma": (30, 50)}
+FILTER_ORDER = 4            # nb1:128
+WINDOW_SIZE_SEC = 1.0       # nb1:131
+OVERLAP_PERCENT = 0.75      # nb1:132
+
+
+def design_bandpass_filter(lowcut, highcut, fs, order=4):
+    """nb1:209-233."""
+    nyquist = 0.5 * fs
+    return signal.butter(order, [lowcut / nyquist, highcut / nyquist], btype="band", output="sos")
+
+
+def _sos_plan(sos):
+    sos = np.ascontiguousarray(sos, dtype=np.float64)
+    n_sections = sos.shape[0]
+    ntaps = 2 * n_sections + 1
+    ntaps -= min((sos[:, 2] == 0).sum(), (sos[:, 5] == 0).sum())      # scipy.signal.sosfiltfilt
+    return sos, np.ascontiguousarray(signal.sosfilt_zi(sos)), int(ntaps * 3)
+
+
+def sosfiltfilt(sos, x, ctx=None):
+    """scipy.signal.sosfiltfilt(sos, x, axis=-1) for a (n_sig, n_samples) float64 array."""
+    ctx = ctx or get_ctx()
+    x = f64(x)
+    one = x.ndim == 1
+    x2 = x.reshape(1, -1) if one else x
+    sos, zi, edge = _sos_plan(sos)
+    if x2.shape[1] <= edge:
+        raise ValueError(f"The length of the input vector x must be greater than padlen, which is {edge}.")
+    y = np.empty_like(x2)
+    ctx.check(ctx.lib.tda_sosfiltfilt(ctx.h, ptr(x2), x2.shape[0], x2.shape[1], ptr(sos), ptr(zi), sos.shape[0], edge,
+                                      ptr(y)))
+    return y[0] if one else y
+
+
+def filtfilt(b, a, x, ctx=None):
+    """scipy.signal.filtfilt(b, a, x, axis=-1) (default odd padding) for (n_sig, n_samples) float64."""
+    ctx = ctx or get_ctx()
+    b = np.ascontiguousarray(np.atleast_1d(b), dtype=np.float64)
+    a = np.ascontiguousarray(np.atleast_1d(a), dtype=np.float64)
+    ntaps = max(len(a), len(b))
+    b = np.concatenate([b, np.zeros(ntaps - len(b))]); a = np.concatenate([a, np.zeros(ntaps - len(a))])
+    zi = np.ascontiguousarray(signal.lfilter_zi(b, a))
+    edge = 3 * ntaps
+    x = f64(x)
+    one = x.ndim == 1
+    x2 = x.reshape(1, -1) if one else x
+    if x2.shape[1] <= edge:
+        raise ValueError(f"The length of the input vector x must be greater than padlen, which is {edge}.")
+    y = np.empty_like(x2)
+    ctx.check(ctx.lib.tda_filtfilt(ctx.h, ptr(x2), x2.shape[0], x2.shape[1], ptr(b), ptr(a), ptr(zi), ntaps, edge, ptr(y)))
+    return y[0] if one else y
+
+
+def apply_bandpass_filter(data, lowcut, highcut, fs, order=4):
+    """nb1:236-263 -- all channels in one launch instead of a Python loop over channels."""
+    return sosfiltfilt(design_bandpass_filter(lowcut, highcut, fs, order), np.asarray(data, dtype=np.float64))
+
+
+def bandpass_filter(s, fs, low, high):
+    """scripts/utils.py:66-74."""
+    nyq = fs / 2
+    lo = max(low / nyq, 0.001)
+    hi = min(high / nyq, 0.999)
+    if lo >= hi:
+        return s
+    b, a = signal.butter(4, [lo, hi], btype="band")
+    return filtfilt(b, a, s)
+
+
+def create_sliding_windows(data, window_size, overlap, fs):
+    """nb1:314-381 -- (n_windows, n_channels, window_samples) stack and window centre times (host slicing;
+    the GPU path never builds this stack, see eeg_to_distances)."""
+    data = np.asarray(data)
+    n_channels, n_samples = data.shape
+    window_samples = int(window_size * fs)
+    step_samples = int(window_samples * (1 - overlap))
+    n_windows = (n_samples - window_samples) // step_samples + 1
+    if n_windows <= 0:
+        return np.zeros((0, n_channels, window_samples)), np.zeros(0)
+    idx = np.arange(n_windows)[:, None] * step_samples + np.arange(window_samples)[None, :]
+    windows = np.ascontiguousarray(data[:, idx].transpose(1, 0, 2))
+    times = (np.arange(n_windows) * step_samples + window_samples // 2) / fs
+    return windows, times
+
+
+def eeg_to_distances(eeg, fs, freq_bands=FREQ_BANDS, window_size=WINDOW_SIZE_SEC, overlap=OVERLAP_PERCENT,
+                     order=FILTER_ORDER, want_corr=False, ctx=None):
+    """raw EEG (n_ch, n_samples) -> {band: (n_win, n_ch, n_ch) distance matrices}; everything between the
+    raw samples and the matrices stays in HBM (torch tensors, one stream)."""
+    import torch
+    ctx = ctx or get_ctx()
+    dev = torch.device("cuda", ctx.device)
+    x = torch.from_numpy(f64(eeg)).to(dev)
+    n_ch, n_s = x.shape
+    win = int(window_size * fs)
+    step = int(win * (1 - overlap))
+    out = {}
+    for name, (lo, hi) in freq_bands.items():
+        sos, zi, edge = _sos_plan(design_bandpass_filter(lo, hi, fs, order))
+        y = torch.empty_like(x)
+        work = torch.empty((n_ch, n_s + 2 * edge), dtype=torch.float64, device=dev)
+        ctx.check(ctx.lib.tda_sosfiltfilt_dev(ctx.h, C.c_void_p(x.data_ptr()), n_ch, n_s, ptr(sos), ptr(zi), sos.shape[0],
+                                              edge, C.c_void_p(y.data_ptr()), C.c_void_p(work.data_ptr()),
+                                              C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+        n_win = (n_s - win) // step + 1 if n_s >= win else 0
+        if n_win <= 0:
+            continue
+        corr_t = torch.empty((n_win, n_ch, n_ch), dtype=torch.float64, device=dev) if want_corr else None
+        dist_t = engine.corr_dist_sliding_dev(y, win, step, corr_t=corr_t, ctx=ctx)
+        out[name] = (corr_t.cpu().numpy(), dist_t.cpu().numpy()) if want_corr else dist_t.cpu().numpy()
+    return out
