@@ -170,6 +170,20 @@ tda_status tda_filtfilt_dev(tda_ctx* ctx, const double* x, int n_sig, int n_samp
 tda_status tda_filtfilt(tda_ctx* ctx, const double* x, int n_sig, int n_samples, const double* b,
                         const double* a, const double* zi, int ntaps, int edge, double* y);
 
+/* Audio front end.  tda_upfirdn replaces scipy.signal.resample_poly(audio, 250, 44100) (scripts/utils.py:77-79):
+ * h (len_h, host-designed exactly as scipy does, incl. its zero padding and the factor `up`),
+ *   y[j] = sum_i x[i] * h[(j + n_pre_remove)*down - i*up],  j < n_out.
+ * tda_hilbert_envelope replaces np.abs(scipy.signal.hilbert(s)) (utils.py:58-59):
+ *   env[n] = sqrt(x[n]^2 + (sum_m x[m] g[(n-m) mod N])^2),  g = imag(ifft(h_hilbert)) tabulated by the host.
+ * float64, agreement with scipy to rounding (1e-12 relative), not bit-identical.  *_dev: all pointers device. */
+tda_status tda_upfirdn_dev(tda_ctx* ctx, const double* x, long long n_in, const double* h, int len_h, int up,
+                           int down, long long n_pre_remove, long long n_out, double* y, void* stream);
+tda_status tda_upfirdn(tda_ctx* ctx, const double* x, long long n_in, const double* h, int len_h, int up,
+                       int down, long long n_pre_remove, long long n_out, double* y);
+tda_status tda_hilbert_envelope_dev(tda_ctx* ctx, const double* x, int n, const double* g, double* env,
+                                    void* stream);
+tda_status tda_hilbert_envelope(tda_ctx* ctx, const double* x, int n, const double* g, double* env);
+
 /* ---- delay from the first zero crossing of the autocorrelation ---------------
  * replaces compute_tau (scripts/utils.py:92-104). max_lag < 0 = None (len/4).         */
 tda_status tda_tau_batch_dev(tda_ctx* ctx, const double* win, int n_win, int n_t, int max_lag,

@@ -52,6 +52,10 @@ SYMBOLS = {
     "tda_sosfiltfilt": (_I, [c_vp, c_vp, _I, _I, c_vp, c_vp, _I, _I, c_vp]),
     "tda_filtfilt_dev": (_I, [c_vp, c_vp, _I, _I, c_vp, c_vp, c_vp, _I, _I, c_vp, c_vp, c_vp]),
     "tda_filtfilt": (_I, [c_vp, c_vp, _I, _I, c_vp, c_vp, c_vp, _I, _I, c_vp]),
+    "tda_upfirdn_dev": (_I, [c_vp, c_vp, C.c_longlong, c_vp, _I, _I, _I, C.c_longlong, C.c_longlong, c_vp, c_vp]),
+    "tda_upfirdn": (_I, [c_vp, c_vp, C.c_longlong, c_vp, _I, _I, _I, C.c_longlong, C.c_longlong, c_vp]),
+    "tda_hilbert_envelope_dev": (_I, [c_vp, c_vp, _I, c_vp, c_vp, c_vp]),
+    "tda_hilbert_envelope": (_I, [c_vp, c_vp, _I, c_vp, c_vp]),
     "tda_tau_batch_dev": (_I, [c_vp, c_vp, _I, _I, _I, c_vp, c_vp]),
     "tda_tau_batch": (_I, [c_vp, c_vp, _I, _I, _I, c_vp]),
     "tda_features_batch_dev": (_I, [c_vp, c_vp, c_vp, _I, _I, c_vp, c_vp]),

@@ -145,6 +145,19 @@ tda_status tda_filtfilt_dev(tda_ctx* ctx, const double* x, int n_sig, int n_samp
     return launch_filtfilt(ctx, x, n_sig, n_samples, b, a, zi, ntaps, edge, y, work, (hipStream_t)stream);
 }
 
+tda_status tda_upfirdn_dev(tda_ctx* ctx, const double* x, long long n_in, const double* h, int len_h, int up, int down,
+                           long long n_pre_remove, long long n_out, double* y, void* stream)
+{
+    CHECK_CTX(ctx); CHECK_PTR(ctx, x); CHECK_PTR(ctx, h); CHECK_PTR(ctx, y);
+    return launch_upfirdn(ctx, x, n_in, h, len_h, up, down, n_pre_remove, n_out, y, (hipStream_t)stream);
+}
+
+tda_status tda_hilbert_envelope_dev(tda_ctx* ctx, const double* x, int n, const double* g, double* env, void* stream)
+{
+    CHECK_CTX(ctx); CHECK_PTR(ctx, x); CHECK_PTR(ctx, g); CHECK_PTR(ctx, env);
+    return launch_hilbert_env(ctx, x, n, g, env, (hipStream_t)stream);
+}
+
 tda_status tda_tau_batch_dev(tda_ctx* ctx, const double* win, int n_win, int n_t, int max_lag, int* tau, void* stream)
 {
     CHECK_CTX(ctx); CHECK_NONNEG(ctx, n_win);
@@ -390,6 +403,37 @@ tda_status tda_filtfilt(tda_ctx* ctx, const double* x, int n_sig, int n_samples,
     s.add((void**)&d_w, nullptr, nullptr, (size_t)n_sig * (n_samples + 2 * edge) * 8);
     RET_IF(s.upload());
     RET_IF(tda_filtfilt_dev(ctx, d_x, n_sig, n_samples, b, a, zi, ntaps, edge, d_y, d_w, nullptr));
+    return s.download();
+}
+
+tda_status tda_upfirdn(tda_ctx* ctx, const double* x, long long n_in, const double* h, int len_h, int up, int down,
+                       long long n_pre_remove, long long n_out, double* y)
+{
+    CHECK_CTX(ctx); CHECK_PTR(ctx, x); CHECK_PTR(ctx, h); CHECK_PTR(ctx, y);
+    if (n_in < 1 || n_out < 1 || len_h < 1) TDA_FAIL(ctx, TDA_ERR_INVALID, "bad sizes");
+    TDA_HIP(ctx, hipSetDevice(ctx->device));
+    Stage s(ctx);
+    double *d_x, *d_h, *d_y;
+    s.add((void**)&d_x, x, nullptr, (size_t)n_in * 8);
+    s.add((void**)&d_h, h, nullptr, (size_t)len_h * 8);
+    s.add((void**)&d_y, nullptr, y, (size_t)n_out * 8);
+    RET_IF(s.upload());
+    RET_IF(tda_upfirdn_dev(ctx, d_x, n_in, d_h, len_h, up, down, n_pre_remove, n_out, d_y, nullptr));
+    return s.download();
+}
+
+tda_status tda_hilbert_envelope(tda_ctx* ctx, const double* x, int n, const double* g, double* env)
+{
+    CHECK_CTX(ctx); CHECK_PTR(ctx, x); CHECK_PTR(ctx, g); CHECK_PTR(ctx, env);
+    if (n < 1) TDA_FAIL(ctx, TDA_ERR_INVALID, "bad sizes");
+    TDA_HIP(ctx, hipSetDevice(ctx->device));
+    Stage s(ctx);
+    double *d_x, *d_g, *d_e;
+    s.add((void**)&d_x, x, nullptr, (size_t)n * 8);
+    s.add((void**)&d_g, g, nullptr, (size_t)n * 8);
+    s.add((void**)&d_e, nullptr, env, (size_t)n * 8);
+    RET_IF(s.upload());
+    RET_IF(tda_hilbert_envelope_dev(ctx, d_x, n, d_g, d_e, nullptr));
     return s.download();
 }
 

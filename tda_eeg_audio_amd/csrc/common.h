@@ -123,6 +123,9 @@ tda_status launch_sosfiltfilt(tda_ctx*, const double*, int, int, const double*, 
                               hipStream_t);
 tda_status launch_filtfilt(tda_ctx*, const double*, int, int, const double*, const double*, const double*, int, int, double*,
                            double*, hipStream_t);
+tda_status launch_upfirdn(tda_ctx*, const double*, long long, const double*, int, int, int, long long, long long, double*,
+                          hipStream_t);
+tda_status launch_hilbert_env(tda_ctx*, const double*, int, const double*, double*, hipStream_t);
 tda_status launch_tau(tda_ctx*, const double*, int, int, int, int*, hipStream_t);
 tda_status launch_features(tda_ctx*, const double*, const int*, int, int, double*, hipStream_t);
 tda_status launch_aggregate(tda_ctx*, const double*, const double*, const int*, int, double*, hipStream_t);

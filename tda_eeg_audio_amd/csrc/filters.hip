@@ -169,3 +169,80 @@ tda_status launch_filtfilt(tda_ctx* ctx, const double* x, int n_sig, int L, cons
     TDA_HIP(ctx, hipGetLastError());
     return TDA_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------
+// Audio front end (scripts/utils.py:56-79): rational resampling and Hilbert envelope.
+//
+//   upfirdn_kernel      replaces scipy.signal.resample_poly(audio, 250, 44100) (utils.py:77-79): the FIR
+//                       low-pass h (Kaiser window, 2*10*max(up,down)+1 taps, padded as scipy pads it) is
+//                       designed on the host with scipy; the kernel evaluates the polyphase sums
+//                         y[j] = sum_i x[i] * h[(j + n_pre_remove)*down - i*up]
+//                       one output sample per thread, i ascending.
+//   hilbert_env_kernel  replaces np.abs(scipy.signal.hilbert(s)) (utils.py:58-59): the analytic signal is
+//                       ifft(fft(x)*h) = x (*) ifft(h) (circular convolution); its real part is x and its
+//                       imaginary part is x (*) g with g = imag(ifft(h)) tabulated on the host, so
+//                         env[n] = sqrt(x[n]^2 + (sum_m x[m] g[(n-m) mod N])^2)
+//                       -- an O(N^2) sum (N ~ 5,000 at 250 Hz), exact to rounding, no FFT needed.
+// Both are float64 sums in a fixed order; agreement with scipy is to rounding (1e-12 relative in the
+// tests), not bit-identical (scipy goes through pocketfft / a different accumulation order).
+// ---------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+upfirdn_kernel(const double* __restrict__ x, long long n_in, const double* __restrict__ h, int len_h, int up, int down,
+               long long n_pre_remove, long long n_out, double* __restrict__ y)
+{
+    const long long j = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (j >= n_out) return;
+    const long long t = (j + n_pre_remove) * down;          // position in the up-sampled domain
+    // taps k = t - i*up in [0, len_h)  <=>  i in [ceil((t-len_h+1)/up), floor(t/up)]
+    long long i_hi = t / up;
+    long long i_lo = t - (len_h - 1);
+    i_lo = i_lo <= 0 ? 0 : (i_lo + up - 1) / up;
+    if (i_hi > n_in - 1) i_hi = n_in - 1;
+    double acc = 0.0;
+    for (long long i = i_lo; i <= i_hi; ++i) acc += x[i] * h[t - i * up];
+    y[j] = acc;
+}
+
+__global__ void __launch_bounds__(256)
+hilbert_env_kernel(const double* __restrict__ x, int n, const double* __restrict__ g, double* __restrict__ env)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    double* xs = reinterpret_cast<double*>(smem);          // x tile
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    double acc = 0.0;
+    for (int m0 = 0; m0 < n; m0 += 256) {
+        const int mm = m0 + threadIdx.x;
+        xs[threadIdx.x] = mm < n ? x[mm] : 0.0;
+        __syncthreads();
+        if (i < n) {
+            const int lim = (n - m0) < 256 ? (n - m0) : 256;
+            int d = i - m0;                                 // (i - m) mod n for m = m0
+            if (d < 0) d += n;
+            for (int q = 0; q < lim; ++q) {
+                acc += xs[q] * g[d];
+                d = d == 0 ? n - 1 : d - 1;
+            }
+        }
+        __syncthreads();
+    }
+    if (i < n) { const double re = x[i]; env[i] = sqrt(re * re + acc * acc); }
+}
+
+tda_status launch_upfirdn(tda_ctx* ctx, const double* x, long long n_in, const double* h, int len_h, int up, int down,
+                          long long n_pre_remove, long long n_out, double* y, hipStream_t st)
+{
+    if (n_out <= 0) return TDA_OK;
+    if (up < 1 || down < 1 || len_h < 1 || n_in < 1) TDA_FAIL(ctx, TDA_ERR_INVALID, "bad resampling geometry");
+    hipLaunchKernelGGL(upfirdn_kernel, dim3((unsigned)((n_out + 255) / 256)), dim3(256), 0, st, x, n_in, h, len_h, up, down,
+                       n_pre_remove, n_out, y);
+    TDA_HIP(ctx, hipGetLastError());
+    return TDA_OK;
+}
+
+tda_status launch_hilbert_env(tda_ctx* ctx, const double* x, int n, const double* g, double* env, hipStream_t st)
+{
+    if (n <= 0) return TDA_OK;
+    hipLaunchKernelGGL(hilbert_env_kernel, dim3((n + 255) / 256), dim3(256), 256 * sizeof(double), st, x, n, g, env);
+    TDA_HIP(ctx, hipGetLastError());
+    return TDA_OK;
+}

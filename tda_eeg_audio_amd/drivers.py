@@ -307,3 +307,11 @@ def save_dataset(features_dir, X, y, subjects, names, filenames):
     np.save(features_dir / "subjects.npy", subjects)
     (features_dir / "feature_names.txt").write_text("".join(f"{n}\n" for n in names))
     (features_dir / "filenames.txt").write_text("".join(f"{n}\n" for n in filenames))
+
+
+def process_recording(audio, eeg_dists_by_band, fs_audio=44100):
+    """cmp:45-124 from the raw audio track (44.1 kHz, as load_audio returns it, utils.py:47-53) and the
+    recording's EEG distance matrices: resample -> envelope -> per-band filter -> windows
+    (preprocess.audio_to_band_windows, all filters on the GPU) -> process_recording_arrays."""
+    from . import preprocess
+    return process_recording_arrays(preprocess.audio_to_band_windows(audio, fs_audio), eeg_dists_by_band)

@@ -135,3 +135,80 @@ def eeg_to_distances(eeg, fs, freq_bands=FREQ_BANDS, window_size=WINDOW_SIZE_SEC
         dist_t = engine.corr_dist_sliding_dev(y, win, step, corr_t=corr_t, ctx=ctx)
         out[name] = (corr_t.cpu().numpy(), dist_t.cpu().numpy()) if want_corr else dist_t.cpu().numpy()
     return out
+
+
+# --------------------------------------------------------------------------------------------
+# audio front end (scripts/utils.py:47-79)
+# --------------------------------------------------------------------------------------------
+FS_AUDIO, FS_EEG = 44100, 250
+
+
+def _resample_plan(n_in, up, down, window=("kaiser", 5.0)):
+    """The FIR design and bookkeeping of scipy.signal.resample_poly (constant padding, cval 0)."""
+    import math
+    g_ = math.gcd(up, down)
+    up //= g_; down //= g_
+    n_out = n_in * up
+    n_out = n_out // down + bool(n_out % down)
+    max_rate = max(up, down)
+    half_len = 10 * max_rate
+    h = signal.firwin(2 * half_len + 1, 1.0 / max_rate, window=window).astype(np.float64)
+    h *= up
+    n_pre_pad = down - half_len % down
+    n_post_pad = 0
+    n_pre_remove = (half_len + n_pre_pad) // down
+
+    def _output_len(len_h, in_len, up_, down_):
+        return (((in_len - 1) * up_ + len_h) - 1) // down_ + 1
+    while _output_len(len(h) + n_pre_pad + n_post_pad, n_in, up, down) < n_out + n_pre_remove:
+        n_post_pad += 1
+    h = np.concatenate((np.zeros(n_pre_pad), h, np.zeros(n_post_pad)))
+    return np.ascontiguousarray(h), up, down, n_pre_remove, n_out
+
+
+def resample_audio(audio, fs_audio=FS_AUDIO, fs_target=FS_EEG, ctx=None):
+    """scripts/utils.py:77-79 -- scipy.signal.resample_poly(audio, fs_target, fs_audio)."""
+    ctx = ctx or get_ctx()
+    x = f64(np.asarray(audio).ravel())
+    if fs_audio == fs_target:
+        return x.copy()
+    h, up, down, n_pre_remove, n_out = _resample_plan(len(x), int(fs_target), int(fs_audio))
+    y = np.empty(n_out)
+    ctx.check(ctx.lib.tda_upfirdn(ctx.h, ptr(x), len(x), ptr(h), len(h), up, down, n_pre_remove, n_out, ptr(y)))
+    return y
+
+
+def hilbert_envelope(s, ctx=None):
+    """np.abs(scipy.signal.hilbert(s)) (utils.py:58-59)."""
+    ctx = ctx or get_ctx()
+    x = f64(np.asarray(s).ravel())
+    n = len(x)
+    hh = np.zeros(n)
+    if n % 2 == 0:
+        hh[0] = hh[n // 2] = 1; hh[1:n // 2] = 2
+    else:
+        hh[0] = 1; hh[1:(n + 1) // 2] = 2
+    g = np.ascontiguousarray(np.fft.ifft(hh).imag)
+    env = np.empty(n)
+    ctx.check(ctx.lib.tda_hilbert_envelope(ctx.h, ptr(x), n, ptr(g), ptr(env)))
+    return env
+
+
+def compute_envelope(s, fs, ctx=None):
+    """scripts/utils.py:56-63 -- Hilbert envelope, then 4th-order low-pass (zero-phase)."""
+    env = hilbert_envelope(s, ctx=ctx)
+    nyq = fs / 2
+    cutoff = min(50, nyq * 0.9)
+    b, a = signal.butter(4, cutoff / nyq, btype="low")
+    return filtfilt(b, a, env, ctx=ctx)
+
+
+def audio_to_band_windows(audio, fs_audio=FS_AUDIO, freq_bands=FREQ_BANDS, ctx=None):
+    """cmp:53-65 -- 44.1 kHz audio -> 250 Hz envelope -> per band zero-phase band-pass -> 1 s windows
+    (step 62): {band: (n_win, 250)}."""
+    from .utils import create_windows
+    rs = resample_audio(audio, fs_audio, FS_EEG, ctx=ctx)
+    env = compute_envelope(rs, FS_EEG, ctx=ctx)
+    win = int(1.0 * FS_EEG)
+    step = int(win * (1 - 0.75))
+    return {name: create_windows(bandpass_filter(env, FS_EEG, lo, hi), win, step) for name, (lo, hi) in freq_bands.items()}

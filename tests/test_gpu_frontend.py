@@ -55,3 +55,35 @@ def test_eeg_to_distances_equals_filter_window_loop(ctx):
         assert windows.shape == (71, 47, 250) and times[0] == 0.5
         _, od = port.corr_dist_batch(windows)
         assert out[name].shape == (71, 47, 47) and np.array_equal(out[name], od), name
+
+
+def test_audio_front_end_vs_scipy(ctx):
+    """resample_poly 44.1 kHz -> 250 Hz, Hilbert envelope + low-pass, per-band windows (cmp:53-65)."""
+    rng = np.random.default_rng(3)
+    n = 44100 * 6 + 1234
+    t_ = np.arange(n) / 44100.0
+    audio = (np.sin(2 * np.pi * 220 * t_) * (1 + 0.5 * np.sin(2 * np.pi * 3 * t_)) + 0.1 * rng.standard_normal(n))
+    ref_rs = signal.resample_poly(audio, 250, 44100)
+    got_rs = preprocess.resample_audio(audio, 44100, 250, ctx=ctx)
+    assert got_rs.shape == ref_rs.shape
+    assert np.abs(got_rs - ref_rs).max() <= 1e-12 * max(1.0, np.abs(ref_rs).max())
+    for m in (len(ref_rs), len(ref_rs) - 1):                    # even and odd lengths
+        s = ref_rs[:m]
+        ref_env = np.abs(signal.hilbert(s))
+        got_env = preprocess.hilbert_envelope(s, ctx=ctx)
+        assert np.abs(got_env - ref_env).max() <= 1e-12 * np.abs(ref_env).max()
+    b, a = signal.butter(4, min(50, 125 * 0.9) / 125, btype="low")
+    ref_env = signal.filtfilt(b, a, np.abs(signal.hilbert(ref_rs)))
+    got_env = preprocess.compute_envelope(ref_rs, 250, ctx=ctx)
+    assert np.abs(got_env - ref_env).max() <= 1e-11 * np.abs(ref_env).max()
+    wins = preprocess.audio_to_band_windows(audio, 44100, ctx=ctx)
+    assert list(wins) == list(preprocess.FREQ_BANDS)
+    n_win = (len(ref_rs) - 250) // 62 + 1
+    for name, (lo, hi) in preprocess.FREQ_BANDS.items():
+        bb, aa = signal.butter(4, [max(lo / 125, 0.001), min(hi / 125, 0.999)], btype="band")
+        # the 8th-order ba-form band-pass (utils.py:73-74) amplifies a 1e-12 input difference by up to
+        # ~1e6 in the delta band (it is ill-conditioned by construction), so the band signals are
+        # compared on the SAME envelope: there the recursion is bit-identical to scipy's
+        ref_band = signal.filtfilt(bb, aa, got_env)
+        assert wins[name].shape == (n_win, 250)
+        assert np.array_equal(wins[name][0], ref_band[:250]) and np.array_equal(wins[name][-1], ref_band[(n_win - 1) * 62:(n_win - 1) * 62 + 250])
