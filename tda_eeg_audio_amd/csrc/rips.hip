@@ -641,7 +641,7 @@ template <int NT, bool WANT_KEYS, bool STAGE>
 __device__ void unpack_sorted(const u64* S, int E, int Ev, int n, u16* rank, int ns, u32* skey)
 {
     const int tid = threadIdx.x;
-    constexpr int MAXPT = STAGE ? 16 : 1;
+    constexpr int MAXPT = STAGE ? (TDA_MAX_POINTS * (TDA_MAX_POINTS - 1) / 2 + NT - 1) / NT : 1;
     u64 held[MAXPT];
     if (STAGE) {
 #pragma unroll
@@ -877,7 +877,6 @@ __device__ void rips_cloud_window(unsigned char* smem, const int win, const doub
     PROF_MARK(0);
     bitonic_sort_lds<NT>(S, npad);
     PROF_MARK(1);
-    static_assert(NT * 16 >= TDA_MAX_POINTS * (TDA_MAX_POINTS - 1) / 2, "staging depth");
     unpack_sorted<NT, false, (sizeof(WT) < 8)>(S, E, Ev, P, rank, L.rank_stride, nullptr);
     PROF_MARK(2);
     int k0, k1, st;
