@@ -220,6 +220,18 @@ tda_status tda_segment_nanmean_dev(tda_ctx* ctx, const double* x, const int* seg
 tda_status tda_segment_nanmean(tda_ctx* ctx, const double* x, const int* seg_off, int n_seg,
                                int n_total, double* out);
 
+/* ---- Spearman correlation of feature time series ------------------------------------
+ * replaces the spearmanr(a_ts, e_ts) loop of process_recording
+ * (scripts/tda_eeg_audio_comparison.py:104-114): per (recording, band) group and per selected
+ * feature column, the Pearson correlation of the average ranks of the audio and EEG series;
+ * r = 0 when the group has < 5 windows or a series has np.std <= 1e-10 (the reference's rule,
+ * which then reports p = 1).  x, y: (n_total, ld) float64; cols: (n_cols) column indices;
+ * r: (n_seg, n_cols).  The p-value is a function of (r, n) only (Student t) and is left to the host. */
+tda_status tda_spearman_batch_dev(tda_ctx* ctx, const double* x, const double* y, int ld, const int* cols,
+                                  int n_cols, const int* seg_off, int n_seg, double* r, void* stream);
+tda_status tda_spearman_batch(tda_ctx* ctx, const double* x, const double* y, int n_total, int ld,
+                              const int* cols, int n_cols, const int* seg_off, int n_seg, double* r);
+
 /* ---- Wasserstein distance between diagrams ------------------------------------
  * replaces safe_wasserstein (scripts/utils.py:180-191) -> persim.wasserstein
  * (order 1, Euclidean ground metric, diagonal cost (d-b)/sqrt 2).

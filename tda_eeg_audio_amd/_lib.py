@@ -64,6 +64,8 @@ SYMBOLS = {
     "tda_aggregate_batch": (_I, [c_vp, c_vp, c_vp, c_vp, _I, _I, c_vp]),
     "tda_segment_nanmean_dev": (_I, [c_vp, c_vp, c_vp, _I, c_vp, c_vp]),
     "tda_segment_nanmean": (_I, [c_vp, c_vp, c_vp, _I, _I, c_vp]),
+    "tda_spearman_batch_dev": (_I, [c_vp, c_vp, c_vp, _I, c_vp, _I, c_vp, _I, c_vp, c_vp]),
+    "tda_spearman_batch": (_I, [c_vp, c_vp, c_vp, _I, _I, c_vp, _I, c_vp, _I, c_vp]),
     "tda_wasserstein_batch_dev": (_I, [c_vp, c_vp, c_vp, _I, c_vp, c_vp, _I, c_vp, c_vp, _I, c_vp, c_vp, c_vp]),
     "tda_wasserstein_batch": (_I, [c_vp, c_vp, c_vp, _I, _I, c_vp, c_vp, _I, _I, c_vp, c_vp, _I, c_vp, c_vp]),
     "tda_event_create": (_I, [c_vp, C.POINTER(c_vp)]),

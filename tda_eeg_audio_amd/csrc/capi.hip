@@ -189,6 +189,14 @@ tda_status tda_segment_nanmean_dev(tda_ctx* ctx, const double* x, const int* seg
     return launch_nanmean(ctx, x, seg_off, n_seg, out, (hipStream_t)stream);
 }
 
+tda_status tda_spearman_batch_dev(tda_ctx* ctx, const double* x, const double* y, int ld, const int* cols, int n_cols,
+                                  const int* seg_off, int n_seg, double* r, void* stream)
+{
+    CHECK_CTX(ctx); CHECK_NONNEG(ctx, n_seg);
+    if (n_seg) { CHECK_PTR(ctx, x); CHECK_PTR(ctx, y); CHECK_PTR(ctx, cols); CHECK_PTR(ctx, seg_off); CHECK_PTR(ctx, r); }
+    return launch_spearman(ctx, x, y, ld, cols, n_cols, seg_off, n_seg, r, (hipStream_t)stream);
+}
+
 tda_status tda_wasserstein_batch_dev(tda_ctx* ctx, const double* dgm_a, const int* cnt_a, int cap_a,
                                      const double* dgm_b, const int* cnt_b, int cap_b, const int* idx_a,
                                      const int* idx_b, int n_pairs, double* out, int* status, void* stream)
@@ -501,6 +509,26 @@ tda_status tda_segment_nanmean(tda_ctx* ctx, const double* x, const int* seg_off
     s.add((void**)&d_out, nullptr, out, (size_t)n_seg * 8);
     RET_IF(s.upload());
     RET_IF(tda_segment_nanmean_dev(ctx, d_x, d_off, n_seg, d_out, nullptr));
+    return s.download();
+}
+
+tda_status tda_spearman_batch(tda_ctx* ctx, const double* x, const double* y, int n_total, int ld, const int* cols,
+                              int n_cols, const int* seg_off, int n_seg, double* r)
+{
+    CHECK_CTX(ctx); CHECK_NONNEG(ctx, n_seg);
+    if (n_seg == 0) return TDA_OK;
+    CHECK_PTR(ctx, x); CHECK_PTR(ctx, y); CHECK_PTR(ctx, cols); CHECK_PTR(ctx, seg_off); CHECK_PTR(ctx, r);
+    if (n_total < 1 || ld < 1 || n_cols < 1) TDA_FAIL(ctx, TDA_ERR_INVALID, "sizes must be >= 1");
+    TDA_HIP(ctx, hipSetDevice(ctx->device));
+    Stage s(ctx);
+    double *d_x, *d_y, *d_r; int *d_c, *d_o;
+    s.add((void**)&d_x, x, nullptr, (size_t)n_total * ld * 8);
+    s.add((void**)&d_y, y, nullptr, (size_t)n_total * ld * 8);
+    s.add((void**)&d_c, cols, nullptr, (size_t)n_cols * 4);
+    s.add((void**)&d_o, seg_off, nullptr, (size_t)(n_seg + 1) * 4);
+    s.add((void**)&d_r, nullptr, r, (size_t)n_seg * n_cols * 8);
+    RET_IF(s.upload());
+    RET_IF(tda_spearman_batch_dev(ctx, d_x, d_y, ld, d_c, n_cols, d_o, n_seg, d_r, nullptr));
     return s.download();
 }
 

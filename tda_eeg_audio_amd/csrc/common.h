@@ -130,5 +130,6 @@ tda_status launch_tau(tda_ctx*, const double*, int, int, int, int*, hipStream_t)
 tda_status launch_features(tda_ctx*, const double*, const int*, int, int, double*, hipStream_t);
 tda_status launch_aggregate(tda_ctx*, const double*, const double*, const int*, int, double*, hipStream_t);
 tda_status launch_nanmean(tda_ctx*, const double*, const int*, int, double*, hipStream_t);
+tda_status launch_spearman(tda_ctx*, const double*, const double*, int, const int*, int, const int*, int, double*, hipStream_t);
 tda_status launch_wasserstein(tda_ctx*, const double*, const int*, int, const double*, const int*, int, const int*,
                               const int*, int, double*, int*, hipStream_t);

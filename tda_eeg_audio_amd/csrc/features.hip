@@ -221,6 +221,65 @@ tda_status launch_nanmean(tda_ctx* ctx, const double* x, const int* seg_off, int
 }
 
 // ---------------------------------------------------------------------------------
+// Spearman correlation of two feature time series per (recording, band) group:
+// scripts/tda_eeg_audio_comparison.py:104-114 -> scipy.stats.spearmanr = Pearson correlation
+// (np.corrcoef) of the average ranks.  x, y: (n_total, ld) rows = windows; column `col`.
+// r = 0 when the group has < 5 windows or either series has np.std <= 1e-10 (cmp:110-114).
+// One thread per (group, column); groups are tiny (<= 15 windows in the reference).
+// ---------------------------------------------------------------------------------
+__global__ void __launch_bounds__(64)
+spearman_kernel(const double* __restrict__ x, const double* __restrict__ y, int ld, const int* __restrict__ cols,
+                int n_cols, const int* __restrict__ seg_off, int n_seg, double* __restrict__ r_out)
+{
+    const int seg = blockIdx.x;
+    const int ci = threadIdx.x;
+    if (seg >= n_seg || ci >= n_cols) return;
+    const int col = cols[ci];
+    const int s0 = seg_off[seg], n = seg_off[seg + 1] - s0;
+    const double* xa = x + (size_t)s0 * ld + col;
+    const double* ya = y + (size_t)s0 * ld + col;
+    double r = 0.0;
+    if (n >= 5) {
+        auto fx = [=](int i) { return xa[(size_t)i * ld]; };
+        auto fy = [=](int i) { return ya[(size_t)i * ld]; };
+        const double mx = np_pairwise_fn(fx, 0, n) / n, my = np_pairwise_fn(fy, 0, n) / n;
+        auto vx = [=](int i) { const double z = xa[(size_t)i * ld] - mx; return z * z; };
+        auto vy = [=](int i) { const double z = ya[(size_t)i * ld] - my; return z * z; };
+        const double sx = sqrt(np_pairwise_fn(vx, 0, n) / n), sy = sqrt(np_pairwise_fn(vy, 0, n) / n);
+        if (sx > 1e-10 && sy > 1e-10) {
+            // average ranks (scipy.stats.rankdata, method="average"), centred: sum of ranks = n(n+1)/2
+            const double mr = 0.5 * (double)(n + 1);
+            double sxx = 0.0, syy = 0.0, sxy = 0.0;
+            for (int i = 0; i < n; ++i) {
+                const double xi = xa[(size_t)i * ld], yi = ya[(size_t)i * ld];
+                int lx = 0, ex = 0, ly = 0, ey = 0;
+                for (int j = 0; j < n; ++j) {
+                    const double xj = xa[(size_t)j * ld], yj = ya[(size_t)j * ld];
+                    lx += xj < xi; ex += xj == xi; ly += yj < yi; ey += yj == yi;
+                }
+                const double rx = (double)lx + 0.5 * (double)(ex + 1) - mr;
+                const double ry = (double)ly + 0.5 * (double)(ey + 1) - mr;
+                sxx += rx * rx; syy += ry * ry; sxy += rx * ry;
+            }
+            r = (sxy / sqrt(sxx)) / sqrt(syy);
+            if (r > 1.0) r = 1.0;
+            if (r < -1.0) r = -1.0;
+        }
+    }
+    r_out[(size_t)seg * n_cols + ci] = r;
+}
+
+tda_status launch_spearman(tda_ctx* ctx, const double* x, const double* y, int ld, const int* cols, int n_cols,
+                           const int* seg_off, int n_seg, double* r_out, hipStream_t st)
+{
+    if (n_seg == 0 || n_cols == 0) return TDA_OK;
+    if (n_cols > 64) TDA_FAIL(ctx, TDA_ERR_UNSUPPORTED, "at most 64 columns");
+    hipLaunchKernelGGL(spearman_kernel, dim3(n_seg), dim3(64), 0, st, x, y, ld, cols, n_cols, seg_off, n_seg, r_out);
+    TDA_HIP(ctx, hipGetLastError());
+    return TDA_OK;
+}
+
+// ---------------------------------------------------------------------------------
 tda_status launch_tau(tda_ctx* ctx, const double* win, int n_win, int n_t, int max_lag, int* tau, hipStream_t st)
 {
     if (n_win == 0) return TDA_OK;

@@ -186,6 +186,9 @@ def process_recording_arrays(audio_band_windows, eeg_dists_by_band):
             "n_windows": int(len(idx)), "tau": tau,
             "audio_h1_features": fa, "eeg_h1_features": fe,
         }
+        r, p = engine.spearman_batch(fa, fe, seg)                       # cmp:104-114
+        out[bname]["feature_correlations"] = {f: {"r": float(r[0, k]), "p": float(p[0, k])}
+                                              for k, f in enumerate(engine.SPEARMAN_FEATURES)}
     return out
 
 

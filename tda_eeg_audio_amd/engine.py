@@ -173,6 +173,39 @@ def segment_nanmean(x, seg_off, ctx=None):
     return out
 
 
+SPEARMAN_FEATURES = ["mean_persistence", "total_persistence", "persistence_entropy", "max_persistence", "n_features"]
+SPEARMAN_COLS = [6, 9, 10, 8, 0]          # their columns in the 11-feature vector (cmp:106-107)
+
+
+def spearman_batch(feat_a, feat_b, seg_off, cols=SPEARMAN_COLS, ctx=None):
+    """r (n_seg, len(cols)) and the two-sided p-value (scipy's Student-t formula on the host)."""
+    ctx = ctx or get_ctx()
+    fa = f64(feat_a); fb = f64(feat_b); off = i32(seg_off); cc = i32(cols)
+    n_seg = len(off) - 1
+    r = np.empty((n_seg, len(cc)))
+    ctx.check(ctx.lib.tda_spearman_batch(ctx.h, ptr(fa), ptr(fb), fa.shape[0], fa.shape[1], ptr(cc), len(cc), ptr(off),
+                                         n_seg, ptr(r)))
+    from scipy import stats
+    n = np.diff(off).astype(float)[:, None]
+    dof = n - 2
+    with np.errstate(divide="ignore", invalid="ignore"):
+        t = r * np.sqrt((dof / ((r + 1.0) * (1.0 - r))).clip(0))
+        p = 2 * stats.t.sf(np.abs(t), dof)
+    # the reference reports r = 0, p = 1 for short or constant series (cmp:113-114)
+    short = (n < 5) | (r == 0.0) & _degenerate(fa, fb, off, cc)
+    p = np.where(short, 1.0, p)
+    return r, p
+
+
+def _degenerate(fa, fb, off, cols):
+    out = np.zeros((len(off) - 1, len(cols)), bool)
+    for s in range(len(off) - 1):
+        a, b = off[s], off[s + 1]
+        for k, c in enumerate(cols):
+            out[s, k] = (b - a) < 5 or np.std(fa[a:b, c]) <= 1e-10 or np.std(fb[a:b, c]) <= 1e-10
+    return out
+
+
 def wasserstein_batch(rows_a, cnt_a, rows_b, cnt_b, idx_a=None, idx_b=None, ctx=None, want_status=False):
     ctx = ctx or get_ctx()
     ra = f64(rows_a); rb = f64(rows_b); ca = i32(cnt_a); cb = i32(cnt_b)

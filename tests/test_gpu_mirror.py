@@ -136,3 +136,26 @@ def test_create_dataset_on_graphs_tree(ctx, tmp_path):
     drivers.save_dataset(tmp_path / "features", X, y, subjects, names, filenames)
     assert np.array_equal(np.load(tmp_path / "features" / "X.npy"), X)
     assert (tmp_path / "features" / "feature_names.txt").read_text().split() == names
+
+
+def test_spearman_matches_scipy(ctx):
+    from scipy.stats import spearmanr
+    from tda_eeg_audio_amd import engine
+    rng = np.random.default_rng(5)
+    n_seg, per = 12, 15
+    fa = rng.random((n_seg * per, 11)); fb = rng.random((n_seg * per, 11))
+    fa[:per, 0] = 3.0                                    # constant series -> r = 0, p = 1 (cmp:113-114)
+    fa[per:2 * per, 0] = np.round(fa[per:2 * per, 0] * 4)   # ties -> average ranks
+    fb[2 * per:3 * per, 6] = fa[2 * per:3 * per, 6]      # identical -> r = 1
+    seg = np.arange(0, n_seg * per + 1, per).astype(np.int32)
+    seg = np.concatenate([seg[:-1], [seg[-1] - 12, seg[-1]]]).astype(np.int32)     # a 3- and a 12-window group
+    r, p = engine.spearman_batch(fa, fb, seg, ctx=ctx)
+    for s in range(len(seg) - 1):
+        a, b = seg[s], seg[s + 1]
+        for k, c in enumerate(engine.SPEARMAN_COLS):
+            x, y = fa[a:b, c], fb[a:b, c]
+            if len(x) >= 5 and np.std(x) > 1e-10 and np.std(y) > 1e-10:
+                rr, pp = spearmanr(x, y)
+            else:
+                rr, pp = 0.0, 1.0
+            assert abs(r[s, k] - rr) < 1e-12 and abs(p[s, k] - pp) < 1e-10, (s, k, r[s, k], rr, p[s, k], pp)
