@@ -45,7 +45,7 @@
 
 // ---- optional phase profiling (make PROFILE=1): cycle sums per phase over all windows ----
 #ifdef TDA_PROFILE
-__device__ unsigned long long g_prof[16];
+__device__ unsigned long long g_prof[24];
 #define PROF_BEGIN() unsigned long long prof_t0 = clock64()
 #define PROF_MARK(i)                                                       \
     do {                                                                   \
@@ -56,9 +56,9 @@ __device__ unsigned long long g_prof[16];
 #define PROF_COUNT(i, v) do { if (threadIdx.x == 0) atomicAdd(&g_prof[i], (unsigned long long)(v)); } while (0)
 extern "C" __attribute__((visibility("default"))) int tda_profile_read(unsigned long long* out, int reset)
 {
-    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_prof), sizeof(unsigned long long) * 16) != hipSuccess) return 1;
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_prof), sizeof(unsigned long long) * 24) != hipSuccess) return 1;
     if (reset) {
-        unsigned long long z[16] = {0};
+        unsigned long long z[24] = {0};
         if (hipMemcpyToSymbol(HIP_SYMBOL(g_prof), z, sizeof(z)) != hipSuccess) return 1;
     }
     return 0;
@@ -77,7 +77,7 @@ extern "C" __attribute__((visibility("default"))) int tda_profile_read(unsigned 
 
 struct SweepShared {
     u64 alive[8];
-    int k0, merges, status, clen;
+    int k0, merges, status, clen, k1, nk, more;
 };
 
 typedef unsigned short pk_u16 __attribute__((ext_vector_type(2)));
@@ -262,10 +262,11 @@ struct RipsLayout {
 #define MISC_WV (512 + 4096 + 128)         // Psi<8> scratch
 #define MISC_MIN (512 + 4096 + 192)        // u32 minkey
 #define MISC_DONE (512 + 4096 + 208)       // u8 done[NT_MAX]
-#define MISC_CKEY (512 + 4096 + 208 + NT_MAX)   // float ckey[NT_MAX]: lengths of this chunk's candidate edges
-#define MISC_SHARED (512 + 4096 + 208 + NT_MAX + 4 * NT_MAX)   // SweepShared (96 B)
-#define MISC_SLOTS (MISC_SHARED + 96)                        // KillSlot<8>[16]: per-wave earliest hit
-#define MISC_ORDC (MISC_SLOTS + 16 * 80)                     // u16 ordc[NT_MAX]: (a<<8|b) of this chunk's edges
+#define MISC_SHARED (512 + 4096 + 208 + NT_MAX)             // SweepShared (96 B)
+#define MISC_CKEY (MISC_SHARED + 96)                         // float ckey[NT_MAX]: lengths of this chunk's candidate edges
+#define MISC_LIST MISC_CKEY                                  // phase d reuses ckey + the tail: triangle list, then kill records
+#define MISC_LIST_BYTES (4 * NT_MAX + 1280)
+#define MISC_ORDC (MISC_LIST + MISC_LIST_BYTES)                     // u16 ordc[NT_MAX]: (a<<8|b) of this chunk's edges
 #define MISC_ADJ (MISC_ORDC + 2 * NT_MAX)                    // u64 adj[128][2]: adjacency bit rows at chunk start
 #define MISC_BYTES (MISC_ADJ + 128 * 16)
 
@@ -504,107 +505,342 @@ __device__ void rips_sweep(int n, int E, int Ev, const u16* rank, int ns, Psi<W,
 #pragma unroll
             for (int w = 0; w < NVW; ++w) rem[w] = 0ull;
             if (apparent) {
-                u64 comp[NVW], fr[NVW];
+                // component of v* in the link: one push from v*, then PULL -- a remaining vertex joins as
+                // soon as one of its neighbours is in the component.  The remaining set is small (mostly
+                // empty after the push), its adjacency reads are independent of each other, and four are
+                // in flight per trip; a push over the (large) frontier would be one dependent LDS read
+                // per vertex.
+                u64 comp[NVW];
 #pragma unroll
                 for (int w = 0; w < NVW; ++w) comp[w] = 0ull;
                 if (NVW == 1 || vstar < 64) comp[0] = 1ull << vstar;
                 else comp[NVW - 1] = 1ull << (vstar - 64);
 #pragma unroll
-                for (int w = 0; w < NVW; ++w) { fr[w] = comp[w]; rem[w] = M[w] & ~comp[w]; }
-                for (int it = 0; it < 128; ++it) {
-                    u64 anyf = 0, anyr = 0;
-#pragma unroll
-                    for (int w = 0; w < NVW; ++w) { anyf |= fr[w]; anyr |= rem[w]; }
-                    if (!anyf || !anyr) break;
-                    int v;
-                    if (NVW == 1 || fr[0]) { v = __builtin_ctzll(fr[0]); fr[0] &= fr[0] - 1; }
-                    else { v = 64 + __builtin_ctzll(fr[NVW - 1]); fr[NVW - 1] &= fr[NVW - 1] - 1; }
+                for (int w = 0; w < NVW; ++w) { comp[w] |= adj[2 * vstar + w] & M[w]; rem[w] = M[w] & ~comp[w]; }
+                bool changed = true;
+                while (changed) {
+                    changed = false;
 #pragma unroll
                     for (int w = 0; w < NVW; ++w) {
-                        const u64 nb = adj[2 * v + w] & rem[w];
-                        rem[w] &= ~nb;
-                        fr[w] |= nb;
+                        u64 rr = rem[w];
+                        while (rr) {
+                            int u[4]; bool ok[4];
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) {
+                                ok[k] = rr != 0ull;
+                                u[k] = ok[k] ? 64 * w + __builtin_ctzll(rr) : vstar;
+                                rr &= rr - 1ull;
+                            }
+                            u64 nb[4][NVW];
+#pragma unroll
+                            for (int k = 0; k < 4; ++k)
+#pragma unroll
+                                for (int x = 0; x < NVW; ++x) nb[k][x] = adj[2 * u[k] + x];
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) {
+                                u64 hit = 0ull;
+#pragma unroll
+                                for (int x = 0; x < NVW; ++x) hit |= nb[k][x] & comp[x];
+                                if (ok[k] && hit) {
+                                    comp[w] |= 1ull << (u[k] & 63);
+                                    rem[w] &= ~(1ull << (u[k] & 63));
+                                    changed = true;
+                                }
+                            }
+                        }
                     }
+                    u64 anyr = 0ull;
+#pragma unroll
+                    for (int w = 0; w < NVW; ++w) anyr |= rem[w];
+                    if (!anyr) break;
                 }
             }
             m0 = (u32)rem[0]; m1 = (u32)(rem[0] >> 32);
             if (NVW == 2) { m2 = (u32)rem[NVW - 1]; m3 = (u32)(rem[NVW - 1] >> 32); }
         }
+        PROF_MARK(16);
+        // All non-trivial triangles of the chunk are listed under the frozen table (key = lane << 8 | v, the
+        // order in which a sequential sweep meets them) and wave 0 reduces the list in registers: the
+        // earliest non-zero vector kills the YOUNGEST class in it (elder rule) and is substituted into
+        // the remaining vectors; the substitutions are linear, so triangles that were trivial stay
+        // trivial and the list is complete.  The psi table is rewritten ONCE per chunk with the
+        // composed substitution.  If the list does not fit, only its earliest entry is processed and
+        // the chunk is listed again.
         const int ta_ = tri2(a), tb_ = tri2(b);
-        bool found = false;
-        int cur_v = 0, ia = 0, ib = 0;
-        for (int guard = 0; guard <= WB * W; ++guard) {
-            // resume / continue the scan
-            if (found) {
+        constexpr int ES = 4 + W * (int)sizeof(WT);                  // list entry: key, vector
+        constexpr int LCAP = (MISC_LIST_BYTES / ES) < 256 ? (MISC_LIST_BYTES / ES) : 256;
+        constexpr int LPL = (LCAP + 63) / 64;
+        // class-indexed image table (one Psi per class) when it fits the list area; else kill records
+        constexpr bool FTAB = WB * W * (int)sizeof(Psi<W, WT>) <= MISC_LIST_BYTES;
+        constexpr int KMAX = FTAB ? 64 : LCAP;                       // kills per reduction round
+        u32* lcnt = reinterpret_cast<u32*>(misc + MISC_MIN);         // [0] entries, [1] earliest key
+        unsigned char* list = misc + MISC_LIST;
+        const u32 mws[4] = {m0, m1, m2, m3};
+        int list_rounds = 0;
+        while (true) {
+            if (tid == 0) { lcnt[0] = 0u; lcnt[1] = 0xffffffffu; }
+            __syncthreads();
+            u32 firstkey = 0xffffffffu;
+            Psi<W, WT> firsty = pzero<W, WT>();
+            if (apparent) {
                 base = psi[tab];
-                const Psi<W, WT> y = pxor(pxor(psi[ia], psi[ib]), base);
-                found = pnz(y);
-            }
-            if (!found) found = scan_word<W, WT>(m0, 0, psi, base, a, b, ta_, tb_, cur_v, ia, ib);
-            if (!found) found = scan_word<W, WT>(m1, 32, psi, base, a, b, ta_, tb_, cur_v, ia, ib);
-            if (NVW == 2) {
-                if (!found) found = scan_word<W, WT>(m2, 64, psi, base, a, b, ta_, tb_, cur_v, ia, ib);
-                if (!found) found = scan_word<W, WT>(m3, 96, psi, base, a, b, ta_, tb_, cur_v, ia, ib);
-            }
-            // earliest non-trivial triangle: per wave on the DPP network, across waves through one
-            // LDS slot per wave (one barrier; slot writes of the next trip come after barrier B)
-            const u32 mykey = found ? (((u32)tid << 8) | (u32)cur_v) : 0xffffffffu;
-            const u32 wmin = wave_min_u32_dpp(mykey);
-            {
-                unsigned char* slot = misc + MISC_SLOTS + 80 * wave;
-                if (found && mykey == wmin) {
-                    *reinterpret_cast<u32*>(slot) = wmin;
-                    *reinterpret_cast<Psi<W, WT>*>(slot + 8) = pxor(pxor(psi[ia], psi[ib]), base);
-                } else if (wmin == 0xffffffffu && lane == 0) {
-                    *reinterpret_cast<u32*>(slot) = 0xffffffffu;
+                Psi<W, WT> prev = pzero<W, WT>();                    // a repeated vector reduces to zero: skip it
+#pragma unroll
+                for (int wi = 0; wi < 2 * NVW; ++wi) {
+                    u32 mm = mws[wi];
+                    const int vbase = 32 * wi;
+                    while (mm) {
+                        const int v0 = vbase + __builtin_ctz(mm); mm &= mm - 1u;
+                        const bool ok1 = mm != 0u; const int v1 = ok1 ? vbase + __builtin_ctz(mm) : v0; mm &= mm - 1u;
+                        const bool ok2 = mm != 0u; const int v2 = ok2 ? vbase + __builtin_ctz(mm) : v0; mm &= mm - 1u;
+                        const bool ok3 = mm != 0u; const int v3 = ok3 ? vbase + __builtin_ctz(mm) : v0; mm &= mm - 1u;
+#define TDA_IDX_(v, ja, jb)                                                       \
+                        const int t##ja = (int)(__umul24((u32)(v), (u32)((v) - 1)) >> 1); \
+                        const int ja = (v) < a ? ta_ + (v) : t##ja + a;                    \
+                        const int jb = (v) < b ? tb_ + (v) : t##ja + b;
+                        TDA_IDX_(v0, ja0, jb0) TDA_IDX_(v1, ja1, jb1) TDA_IDX_(v2, ja2, jb2) TDA_IDX_(v3, ja3, jb3)
+#undef TDA_IDX_
+                        const Psi<W, WT> p0 = psi[ja0], q0 = psi[jb0], p1 = psi[ja1], q1_ = psi[jb1];
+                        const Psi<W, WT> p2 = psi[ja2], q2_ = psi[jb2], p3 = psi[ja3], q3 = psi[jb3];
+                        const Psi<W, WT> ys[4] = {pxor(pxor(p0, q0), base), pxor(pxor(p1, q1_), base),
+                                                  pxor(pxor(p2, q2_), base), pxor(pxor(p3, q3), base)};
+                        const bool oks[4] = {true, ok1, ok2, ok3};
+                        const int vs[4] = {v0, v1, v2, v3};
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            if (!oks[k] || !pnz(ys[k]) || !pnz(pxor(ys[k], prev))) continue;
+                            prev = ys[k];
+                            const u32 key = ((u32)tid << 8) | (u32)vs[k];
+                            if (firstkey == 0xffffffffu) { firstkey = key; firsty = ys[k]; }
+                            const u32 idx = atomicAdd(&lcnt[0], 1u);
+                            if (idx < (u32)LCAP) {
+                                *reinterpret_cast<u32*>(list + ES * idx) = key;
+#pragma unroll
+                                for (int c = 0; c < W; ++c)
+                                    *reinterpret_cast<WT*>(list + ES * idx + 4 + c * (int)sizeof(WT)) = ys[k].w[c];
+                            }
+                        }
+                    }
                 }
             }
-            __syncthreads();                                   // barrier A
-            u32 mk = 0xffffffffu;
-            int mwv = 0;
-#pragma unroll
-            for (int w8 = 0; w8 < NT / 64; ++w8) {
-                const u32 kk = *reinterpret_cast<const u32*>(misc + MISC_SLOTS + 80 * w8);
-                if (kk < mk) { mk = kk; mwv = w8; }
+            {
+                const u32 wmin = wave_min_u32_dpp(firstkey);
+                if (lane == 0 && wmin != 0xffffffffu) atomicMin(&lcnt[1], wmin);
             }
-            if (mk == 0xffffffffu) break;
-            // ---- kill: the earliest non-trivial triangle of the chunk ----
-            const Psi<W, WT> wv = *reinterpret_cast<const Psi<W, WT>*>(misc + MISC_SLOTS + 80 * mwv + 8);
-            const int rk = r0 + (int)(mk >> 8);
-            // youngest class of wv: lane i looks at bit i of every word (each wave redundantly)
-            int candv = -1;
-            const int lb = lane & (WB - 1);
-#pragma unroll
-            for (int c = 0; c < W; ++c)
-                if (lane < WB && ((wv.w[c] >> lb) & (WT)1)) { const int br = brank[WB * c + lb]; candv = br > candv ? br : candv; }
-            const int best = wave_max_i32_dpp(candv);
-            int ybit = 0, ycw = 0;
-#pragma unroll
-            for (int c = W - 1; c >= 0; --c) {
-                const u64 bal = __ballot(lane < WB && ((wv.w[c] >> lb) & (WT)1) && brank[WB * c + lb] == best);
-                if (bal) { ycw = c; ybit = __builtin_ctzll(bal); }
-            }
-            const float ybirth = bkey[WB * ycw + ybit];
-            const u32 pkk = ordc[rk - r0];
-            const float key = keyfn(rk, (int)(pkk >> 8), (int)(pkk & 255u));
-            if (key > ybirth) {
-                if (k1 < h1_cap && tid == 0) { h1[2 * k1] = (double)ybirth; h1[2 * k1 + 1] = (double)key; }
-                ++k1;
-            }
-#pragma unroll 4
-            for (int e = tid; e < E; e += NT) {
-                Psi<W, WT> p = psi[e];
-                WT sel = 0;
-#pragma unroll
-                for (int c = 0; c < W; ++c)
-                    if (c == ycw) sel = (p.w[c] >> ybit) & (WT)1;
-                if (sel) psi[e] = pxor(p, wv);
-            }
-#pragma unroll
-            for (int c = 0; c < W; ++c)
-                if (c == ycw) alive[c] &= (WT)~((WT)1 << ybit);
             __syncthreads();
-            PROF_COUNT(10, 1);
+            PROF_MARK(17);
+            const u32 cnt = lcnt[0];
+            if (cnt == 0u) break;
+            const bool complete = cnt <= (u32)LCAP;
+            PROF_COUNT(11, 1);
+            PROF_COUNT(12, cnt);
+            if (!complete) {
+                PROF_COUNT(13, 1);
+                if (firstkey == lcnt[1]) {                            // exactly one lane: keys are unique
+                    *reinterpret_cast<u32*>(list) = firstkey;
+#pragma unroll
+                    for (int c = 0; c < W; ++c) *reinterpret_cast<WT*>(list + 4 + c * (int)sizeof(WT)) = firsty.w[c];
+                }
+                __syncthreads();
+            }
+            WT alive_before[W];                                      // wave 0 updates `alive` while it reduces
+#pragma unroll
+            for (int c = 0; c < W; ++c) alive_before[c] = alive[c];
+            if (wave == 0) {
+                const int nl = complete ? (int)cnt : 1;
+                u32 ek[LPL];
+                Psi<W, WT> ev[LPL];
+#pragma unroll
+                for (int q = 0; q < LPL; ++q) {
+                    const int idx = lane + 64 * q;
+                    ek[q] = 0xffffffffu; ev[q] = pzero<W, WT>();
+                    if (idx < nl) {
+                        ek[q] = *reinterpret_cast<const u32*>(list + ES * idx);
+#pragma unroll
+                        for (int c = 0; c < W; ++c)
+                            ev[q].w[c] = *reinterpret_cast<const WT*>(list + ES * idx + 4 + c * (int)sizeof(WT));
+                    }
+                }
+                // birth rank / length of the classes: lane i keeps bit i of every word
+                const int lb = lane & (WB - 1);
+                int brk[W];
+                float bky[W];
+#pragma unroll
+                for (int c = 0; c < W; ++c) {
+                    brk[c] = lane < WB ? brank[WB * c + lb] : -1;
+                    bky[c] = lane < WB ? bkey[WB * c + lb] : 0.f;
+                }
+                // FTAB: lane j keeps kill j -- the image of its class under all LATER kills (composed
+                // substitution), the rank of the killing edge and the birth length
+                Psi<W, WT> vimg = pzero<W, WT>();
+                u32 mycode = 0u, myrk = 0u;
+                float mybirth = 0.f;
+                int nk = 0, more = 0;
+                while (true) {
+                    u32 mk = 0xffffffffu;
+#pragma unroll
+                    for (int q = 0; q < LPL; ++q)
+                        if (pnz(ev[q]) && ek[q] < mk) mk = ek[q];
+                    const u32 best = wave_min_u32_dpp(mk);
+                    if (best == 0xffffffffu) break;
+                    if (nk == KMAX) { more = 1; break; }
+                    const int src = __builtin_ctzll(__ballot(mk == best));
+                    Psi<W, WT> mine = pzero<W, WT>();
+#pragma unroll
+                    for (int q = 0; q < LPL; ++q)
+                        if (ek[q] == best) mine = ev[q];
+                    Psi<W, WT> wv;
+#pragma unroll
+                    for (int c = 0; c < W; ++c) {
+                        if (sizeof(WT) == 8) wv.w[c] = (WT)rl64((u64)mine.w[c], src);
+                        else wv.w[c] = (WT)rl32((u32)mine.w[c], src);
+                    }
+                    const int rk = r0 + (int)(best >> 8);
+                    // youngest class of wv (elder rule)
+                    int candv = -1, cwl = 0;
+                    float byl = 0.f;
+#pragma unroll
+                    for (int c = 0; c < W; ++c)
+                        if (lane < WB && ((wv.w[c] >> lb) & (WT)1) && brk[c] > candv) { candv = brk[c]; cwl = c; byl = bky[c]; }
+                    const int bestr = wave_max_i32_dpp(candv);
+                    const u64 ybal = __ballot(candv == bestr && candv >= 0);                     // birth ranks are distinct
+                    if (!ybal) { status |= TDA_WIN_CLASS_OVERFLOW; break; }                      // cannot happen: never spin
+                    const int ybit = __builtin_ctzll(ybal);
+                    const int ycw = (int)rl32((u32)cwl, ybit);
+                    const float ybirth = __uint_as_float(rl32(__float_as_uint(byl), ybit));
+                    if (FTAB) {
+                        WT sel = 0;
+#pragma unroll
+                        for (int c = 0; c < W; ++c)
+                            if (c == ycw) sel = (vimg.w[c] >> ybit) & (WT)1;
+                        if (lane < nk && sel) vimg = pxor(vimg, wv);
+                        if (lane == nk) {
+                            vimg = wv;
+#pragma unroll
+                            for (int c = 0; c < W; ++c)
+                                if (c == ycw) vimg.w[c] &= (WT)~((WT)1 << ybit);
+                            mycode = ((u32)ycw << 8) | (u32)ybit; myrk = (u32)rk; mybirth = ybirth;
+                        }
+                    } else {
+                        const u32 pkk = ordc[rk - r0];
+                        const float key = keyfn(rk, (int)(pkk >> 8), (int)(pkk & 255u));
+                        if (key > ybirth) {
+                            if (k1 < h1_cap && lane == 0) { h1[2 * k1] = (double)ybirth; h1[2 * k1 + 1] = (double)key; }
+                            ++k1;
+                        }
+                        if (lane == 0) {                              // kill record nk (the list is in registers by now)
+                            *reinterpret_cast<u32*>(list + ES * nk) = ((u32)ycw << 8) | (u32)ybit;
+#pragma unroll
+                            for (int c = 0; c < W; ++c) *reinterpret_cast<WT*>(list + ES * nk + 4 + c * (int)sizeof(WT)) = wv.w[c];
+                        }
+                    }
+                    // substitute into the vectors still waiting (the killer itself becomes zero)
+#pragma unroll
+                    for (int q = 0; q < LPL; ++q) {
+                        WT sel = 0;
+#pragma unroll
+                        for (int c = 0; c < W; ++c)
+                            if (c == ycw) sel = (ev[q].w[c] >> ybit) & (WT)1;
+                        if (sel) ev[q] = pxor(ev[q], wv);
+                    }
+#pragma unroll
+                    for (int c = 0; c < W; ++c)
+                        if (c == ycw) alive[c] &= (WT)~((WT)1 << ybit);
+                    ++nk;
+                    PROF_COUNT(10, 1);
+                }
+                if (FTAB) {
+                    // diagram rows of this round, one kill per lane; the image table for the rewrite
+                    const bool mine_ok = lane < nk;
+                    float key = 0.f;
+                    if (mine_ok) {
+                        const u32 pkk = ordc[(int)myrk - r0];
+                        key = keyfn((int)myrk, (int)(pkk >> 8), (int)(pkk & 255u));
+                    }
+                    const bool emit = mine_ok && key > mybirth;
+                    const u64 bal = __ballot(emit);
+                    const int pos = k1 + __builtin_popcountll(bal & ((1ull << lane) - 1ull));
+                    if (emit && pos < h1_cap) { h1[2 * pos] = (double)mybirth; h1[2 * pos + 1] = (double)key; }
+                    k1 += __builtin_popcountll(bal);
+                    if (mine_ok) {
+                        Psi<W, WT>* ftab = reinterpret_cast<Psi<W, WT>*>(list);
+                        ftab[WB * (int)(mycode >> 8) + (int)(mycode & 255u)] = vimg;
+                    }
+                }
+                if (lane == 0) {
+#pragma unroll
+                    for (int c = 0; c < W; ++c) shared->alive[c] = (u64)alive[c];
+                    shared->k1 = k1; shared->nk = nk; shared->more = more; shared->status = status;
+                }
+            }
+            __syncthreads();
+            PROF_MARK(18);
+            WT kmask[W];
+#pragma unroll
+            for (int c = 0; c < W; ++c) { const WT na = (WT)shared->alive[c]; kmask[c] = alive_before[c] & (WT)~na; alive[c] = na; }
+            k1 = shared->k1;
+            const int nk = shared->nk;
+            const bool more = shared->more != 0;
+            status = shared->status;
+            if (status) break;
+            if (FTAB) {
+                // ---- rewrite: p -> (p minus killed classes) ^ images of the killed classes it contained ----
+                const Psi<W, WT>* ftab = reinterpret_cast<const Psi<W, WT>*>(list);
+#pragma unroll 4
+                for (int e = tid; e < E; e += NT) {
+                    const Psi<W, WT> p = psi[e];
+                    WT anyh = 0;
+#pragma unroll
+                    for (int c = 0; c < W; ++c) anyh |= p.w[c] & kmask[c];
+                    if (!anyh) continue;
+                    Psi<W, WT> q;
+#pragma unroll
+                    for (int c = 0; c < W; ++c) q.w[c] = p.w[c] & (WT)~kmask[c];
+#pragma unroll
+                    for (int c = 0; c < W; ++c) {
+                        u64 hh = (u64)(p.w[c] & kmask[c]);
+                        while (hh) {
+                            const int bit = __builtin_ctzll(hh);
+                            hh &= hh - 1ull;
+                            q = pxor(q, ftab[WB * c + bit]);
+                        }
+                    }
+                    psi[e] = q;
+                }
+            } else {
+                // ---- the composed substitution, four kills per pass over the table ----
+                for (int j0 = 0; j0 < nk; j0 += 4) {
+                    u32 kc[4];
+                    Psi<W, WT> kw[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int jj = j0 + j < nk ? j0 + j : j0;
+                        kc[j] = j0 + j < nk ? *reinterpret_cast<const u32*>(list + ES * jj) : 0xffffffffu;
+#pragma unroll
+                        for (int c = 0; c < W; ++c) kw[j].w[c] = *reinterpret_cast<const WT*>(list + ES * jj + 4 + c * (int)sizeof(WT));
+                    }
+#pragma unroll 4
+                    for (int e = tid; e < E; e += NT) {
+                        Psi<W, WT> p = psi[e];
+                        bool changed = false;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            if (kc[j] == 0xffffffffu) continue;
+                            const int jcw = (int)(kc[j] >> 8), jbit = (int)(kc[j] & 255u);
+                            WT sel = 0;
+#pragma unroll
+                            for (int c = 0; c < W; ++c)
+                                if (c == jcw) sel = (p.w[c] >> jbit) & (WT)1;
+                            if (sel) { p = pxor(p, kw[j]); changed = true; }
+                        }
+                        if (changed) psi[e] = p;
+                    }
+                }
+            }
+            PROF_MARK(19);
+            if (complete && !more) break;
+            if (++list_rounds > 4 * NT) { status |= TDA_WIN_CLASS_OVERFLOW; break; }   // every round kills >= 1 class: never reached
+            __syncthreads();            // table rewritten before the chunk is listed again
         }
         // the chunk's edges join the adjacency rows
         if (valid && tid < clen) {

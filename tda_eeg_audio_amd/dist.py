@@ -30,6 +30,21 @@ def shard_recordings(n_windows, world_size):
     return [np.array(sorted(s), dtype=np.int64) for s in shards]
 
 
+_IDX_CACHE = {}
+
+
+def _index_tensor(rows, device):
+    """Row-index tensor on `device`, uploaded once per distinct index list (a pageable H2D copy per
+    step would put a host synchronisation into the timed loop)."""
+    import torch
+    key = (device, np.asarray(rows, np.int64).tobytes())
+    t = _IDX_CACHE.get(key)
+    if t is None:
+        t = torch.as_tensor(np.asarray(rows, np.int64), device=device)
+        _IDX_CACHE[key] = t
+    return t
+
+
 def all_gather_rows(local_rows, my_recs, shards, n_total, group=None):
     """local_rows: (len(my_recs), k) tensor of this rank's results, rows in the order of
     shards[rank].  Returns the (n_total, k) tensor in original recording order on every rank."""
@@ -39,7 +54,7 @@ def all_gather_rows(local_rows, my_recs, shards, n_total, group=None):
     k = local_rows.shape[1]
     if world == 1:
         out = torch.empty((n_total, k), dtype=local_rows.dtype, device=local_rows.device)
-        out[torch.as_tensor(my_recs, device=local_rows.device)] = local_rows
+        out[_index_tensor(my_recs, local_rows.device)] = local_rows
         return out
     pad = max(len(s) for s in shards)
     send = torch.zeros((pad, k), dtype=local_rows.dtype, device=local_rows.device)
@@ -55,7 +70,7 @@ def all_gather_rows(local_rows, my_recs, shards, n_total, group=None):
     out = torch.empty((n_total, k), dtype=local_rows.dtype, device=local_rows.device)
     for r, s in enumerate(shards):
         if len(s):
-            out[torch.as_tensor(s, device=local_rows.device)] = recv[r * pad: r * pad + len(s)]
+            out[_index_tensor(s, local_rows.device)] = recv[r * pad: r * pad + len(s)]
     return out
 
 

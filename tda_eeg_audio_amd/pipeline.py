@@ -103,5 +103,41 @@ def run_step(eeg_win, audio_win, ws, ctx=None, max_lag=125, timers=None):
     return ws.result
 
 
+class Lanes:
+    """`depth` independent (Workspace, stream pair) lanes.  Consecutive batches (recording-bands are
+    independent, cmp:77-122 runs them one after the other) go to alternating lanes, so that the
+    thin tail of one batch's grids -- 710 workgroups on 256 CUs is 1.4 rounds of the audio Rips
+    kernel -- is filled by the head of the next batch instead of leaving CUs idle.  Every lane owns
+    its buffers; results of a lane are complete when its stream has drained (`drain`)."""
+
+    def __init__(self, depth, n_win, seg_off, device, **kw):
+        import torch
+        self.depth = max(1, int(depth))
+        self.ws = [Workspace(n_win, seg_off, device, **kw) for _ in range(self.depth)]
+        self.streams = [torch.cuda.Stream(device=device) for _ in range(self.depth)]
+        self.k = 0
+
+    def submit(self, eeg_win, audio_win, ctx=None, max_lag=125, timers=None, post=None):
+        """Enqueue one step on the next lane; returns that lane's result tensor (valid after
+        `drain` or a wait on the lane's stream).  `post(result)` runs on the lane's stream too
+        (e.g. the all-gather of the result rows)."""
+        import torch
+        i = self.k % self.depth
+        self.k += 1
+        st = self.streams[i]
+        st.wait_stream(torch.cuda.current_stream())         # inputs produced on the caller's stream
+        with torch.cuda.stream(st):
+            res = run_step(eeg_win, audio_win, self.ws[i], ctx=ctx, max_lag=max_lag, timers=timers)
+            if post is not None:
+                res = post(res)
+        return res
+
+    def drain(self):
+        import torch
+        cur = torch.cuda.current_stream()
+        for st in self.streams:
+            cur.wait_stream(st)
+
+
 STAGES = ["corr_dist", "rips_eeg", "features_eeg", "tau", "rips_audio", "features_audio", "wasserstein_h0",
           "wasserstein_h1", "reduce"]
