@@ -13,11 +13,13 @@
 //  P0  all n(n-1)/2 float32 edge lengths are packed as (sortable key << 16 | a << 8 | b); edges
 //      longer than min(thresh, enclosing radius) are dropped (they cannot contribute a row);
 //  P1  bitonic sort in LDS (whole workgroup, two butterfly stages per pass);
-//  P2  rank[a][b] = r for the r-th edge (0x7fff for absent edges) -- adjacency "at time r" becomes
-//      the comparison rank < r; no rank -> edge table is kept;
+//  P2  rank[(a,b)] = r for the r-th edge (triangular u16 table, 0x7fff for edges beyond the effective
+//      threshold) and ord[r] = (a,b);
 //  P3  sweep over the filtration in chunks of NT consecutive edges, ONE EDGE PER LANE:
-//      a. common-neighbour mask  M_r = { v : rank[a][v] < r and rank[b][v] < r }  (packed 16-bit
-//         compares, 16 vertices per trip) -- no sequential adjacency state;
+//      a. common-neighbour mask M_r = { v : (a,v) and (b,v) older than r }: the adjacency bit rows of
+//         the chunk start give the bulk; a vertex can only have become common since then through an
+//         edge of this chunk, and those few candidates (bit rows of the chunk's own edges) are
+//         confirmed with two rank look-ups -- no sequential adjacency state inside a chunk;
 //      b. edges with M_r = 0 are the only candidates for negative (spanning-forest) edges: wave 0
 //         walks them in rank order with the component labels in registers and decides
 //                                      merge -> H0 death at |e|   /   else -> a new H1 class is born;
@@ -30,7 +32,9 @@
 //         (closure over adjacency bit rows) are tested: psi[e]^psi[a,v]^psi[b,v].  The earliest
 //         non-zero one in the chunk kills the YOUNGEST class in it (elder rule): that class is
 //         substituted out of the whole psi table and the pair (birth, |e|) is emitted.  This happens
-//         exactly once per H1 class that ever dies (tens per window).
+//         exactly once per H1 class that ever dies (tens per window).  All non-trivial triangles of a
+//         chunk are listed at once; wave 0 reduces the list in registers (the substitutions are
+//         linear maps) and the psi table is rewritten once per chunk through a class -> image table.
 //      The multiset of (birth,death) pairs equals that of any persistence algorithm on the
 //      same filtration; tie order inside equal diameters does not change it.
 //  P4  rows are written as float64 (float32-exact) pairs: H0 ascending death then the essential
@@ -249,47 +253,45 @@ struct RipsOut {
 };
 
 struct RipsLayout {
-    int off_rank, off_aux, off_misc;            // psi (and the sort array) start at 0
-    int rank_stride;                            // u16 elements per rank row (multiple of 4)
+    int off_rank, off_ord, off_aux, off_misc;   // psi (and the sort array) start at 0
     int total;
 };
 
-// misc block (byte offsets inside off_misc)
-#define MISC_COMP 0                        // int comp[128]
-#define MISC_BRANK 512                     // int brank[512]   (up to 8 class words)
-#define MISC_BKEY (512 + 2048)             // float bkey[512]
-#define MISC_CAND (512 + 4096)             // u64 cand[16]
-#define MISC_WV (512 + 4096 + 128)         // Psi<8> scratch
-#define MISC_MIN (512 + 4096 + 192)        // u32 minkey
-#define MISC_DONE (512 + 4096 + 208)       // u8 done[NT_MAX]
-#define MISC_SHARED (512 + 4096 + 208 + NT_MAX)             // SweepShared (96 B)
+// misc block (byte offsets inside off_misc); the class tables at its end are sized by the variant
+#define MISC_COMP 0                                          // int comp[128] / u32 vmax[128] (before the sweep)
+#define MISC_CAND 512                                        // u64 cand[16]
+#define MISC_WV (512 + 128)                                  // 64 B scratch
+#define MISC_MIN (512 + 192)                                 // u32[4]: reductions; list count / earliest key
+#define MISC_DONE (512 + 208)                                // u8 done[NT_MAX]
+#define MISC_SHARED (MISC_DONE + NT_MAX)                     // SweepShared (96 B)
 #define MISC_CKEY (MISC_SHARED + 96)                         // float ckey[NT_MAX]: lengths of this chunk's candidate edges
-#define MISC_LIST MISC_CKEY                                  // phase d reuses ckey + the tail: triangle list, then kill records
+#define MISC_LIST MISC_CKEY                                  // phase d reuses ckey + the tail: triangle list, then image table
 #define MISC_LIST_BYTES (4 * NT_MAX + 1280)
-#define MISC_ORDC (MISC_LIST + MISC_LIST_BYTES)                     // u16 ordc[NT_MAX]: (a<<8|b) of this chunk's edges
-#define MISC_ADJ (MISC_ORDC + 2 * NT_MAX)                    // u64 adj[128][2]: adjacency bit rows at chunk start
-#define MISC_BYTES (MISC_ADJ + 128 * 16)
+#define MISC_ADJ (MISC_LIST + MISC_LIST_BYTES)               // u64 adj[128][2]: adjacency bit rows at chunk start
+#define MISC_ADJC (MISC_ADJ + 128 * 16)                      // u64 adjc[128][2]: adjacency bit rows of the chunk's own edges
+#define MISC_BRANK (MISC_ADJC + 128 * 16)                    // int brank[ncls], then float bkey[ncls]
+#define MISC_BYTES(ncls) (MISC_BRANK + 8 * (ncls))
 
 // ---------------------------------------------------------------------------------
 // The sweep (phase P3).  KEYFN(r, a, b) returns the float32 length of sorted edge r = (a,b).
 // All control flow is workgroup-uniform; ord/rank/psi/misc live in LDS.
 // ---------------------------------------------------------------------------------
 template <int NT, int NVW, int W, typename WT, class KEYFN>
-__device__ void rips_sweep(int n, int E, int Ev, const u16* rank, int ns, Psi<W, WT>* psi,
+__device__ void rips_sweep(int n, int E, int Ev, const u16* rank, const u16* ord, Psi<W, WT>* psi,
                            unsigned char* misc, KEYFN keyfn, double* h0, int h0_cap, double* h1, int h1_cap,
                            int& out_k0, int& out_k1, int& out_status)
 {
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     int* brank = reinterpret_cast<int*>(misc + MISC_BRANK);
-    float* bkey = reinterpret_cast<float*>(misc + MISC_BKEY);
     u64* cand = reinterpret_cast<u64*>(misc + MISC_CAND);
     unsigned char* done = misc + MISC_DONE;
     float* ckey = reinterpret_cast<float*>(misc + MISC_CKEY);
     SweepShared* shared = reinterpret_cast<SweepShared*>(misc + MISC_SHARED);
-    u16* ordc = reinterpret_cast<u16*>(misc + MISC_ORDC);
     u64* adj = reinterpret_cast<u64*>(misc + MISC_ADJ);      // adj[2*v + w]: neighbours of v among vertices 64w..64w+63
     constexpr int WB = 8 * (int)sizeof(WT);          // class bits per word
+    float* bkey = reinterpret_cast<float*>(misc + MISC_BRANK + 4 * WB * W);
+    u64* adjc = reinterpret_cast<u64*>(misc + MISC_ADJC);    // adjc[2*v + w]: neighbours of v through edges of this chunk
 
     for (int e = tid; e < E; e += NT) psi[e] = pzero<W, WT>();
     for (int i = tid; i < WB * W; i += NT) { brank[i] = -1; bkey[i] = 0.f; }
@@ -300,9 +302,6 @@ __device__ void rips_sweep(int n, int E, int Ev, const u16* rank, int ns, Psi<W,
 #pragma unroll
     for (int c = 0; c < W; ++c) alive[c] = 0;
     int k0 = 0, k1 = 0, merges = 0, status = 0;
-    // walk of the rank matrix in 64-bit groups: item = (row a, group g); advanced without divisions
-    const int G = ns >> 2;
-    const int it_a0 = tid / G, it_g0 = tid - (tid / G) * G, it_da = NT / G, it_dg = NT - (NT / G) * G;
     int compA = lane, compB = lane + 64;     // component labels of vertices lane / lane+64 (used by wave 0)
 
     int clen = NT;
@@ -310,66 +309,44 @@ __device__ void rips_sweep(int n, int E, int Ev, const u16* rank, int ns, Psi<W,
     for (int r0 = 0; r0 < Ev && !status; r0 += clen) {
         clen = NT;
         PROF_MARK(15);
-        // the chunk's edges (a,b) are recovered from the rank matrix (no rank -> edge table is kept)
-        ordc[tid] = (u16)0x0100;
-        __syncthreads();
-        {
-            const u64* rank64 = reinterpret_cast<const u64*>(rank);
-            int ia_ = it_a0, ig_ = it_g0;
-            for (int item = tid; item < n * G; item += NT) {
-                const u64 x = rank64[item];
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const int d = (int)((x >> (16 * k)) & 0xffffull) - r0;
-                    const int bb = 4 * ig_ + k;
-                    if ((unsigned)d < (unsigned)NT && bb < ia_) ordc[d] = (u16)((ia_ << 8) | bb);
-                }
-                ia_ += it_da; ig_ += it_dg;
-                if (ig_ >= G) { ig_ -= G; ++ia_; }
-            }
-        }
+        if (tid < 256) adjc[tid] = 0ull;
         __syncthreads();
         const int r = r0 + tid;
         const bool valid = r < Ev;
         int a = 1, b = 0;
-        if (valid) { const u32 pk = ordc[tid]; a = (int)(pk >> 8); b = (int)(pk & 255u); }
+        if (valid) { const u32 pk = ord[r]; a = (int)(pk >> 8); b = (int)(pk & 255u); }     // ord[r] = (a << 8 | b), a > b
         const int tab = tri2(a) + b;
+        // adjacency rows of the chunk's own edges (whatever their position in the chunk)
+        if (valid) {
+            atomicOr(reinterpret_cast<unsigned long long*>(&adjc[2 * a + (b >> 6)]), 1ull << (b & 63));
+            atomicOr(reinterpret_cast<unsigned long long*>(&adjc[2 * b + (a >> 6)]), 1ull << (a & 63));
+        }
+        __syncthreads();
         // ---- a. common-neighbour mask from the rank rows of a and b ----
         u64 M[NVW], M0[NVW];     // M: common neighbours before edge r; M0: those already common at chunk start
 #pragma unroll
         for (int w = 0; w < NVW; ++w) { M[w] = 0; M0[w] = 0; }
         if (valid) {
-            // packed 16-bit compare, 16 vertices per trip: max(rank[a][v], rank[b][v]) - r is negative
-            // exactly when both edges are older than r (ranks <= 0x7fff).  v_pk_max_u16 / v_pk_sub_i16 /
-            // v_pk_ashrrev_i16 handle two vertices per instruction.
-            const u64* ra = reinterpret_cast<const u64*>(rank + a * ns);
-            const u64* rb = reinterpret_cast<const u64*>(rank + b * ns);
-            const pk_u16 rr2 = {(u16)r, (u16)r};
-            const int chunks = (n + 15) >> 4;
-            for (int c16 = 0; c16 < chunks; ++c16) {
-                u32 acc = 0;
+            // Common neighbours at chunk start come from the adjacency bit rows.  A vertex can only have
+            // become common since then through an edge of this chunk: those few candidates (bit rows of
+            // the chunk's edges) are confirmed against the rank matrix -- both edges older than r.
+            const int ta0 = tri2(a), tb0 = tri2(b);
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const u64 xa = ra[4 * c16 + q], xb = rb[4 * c16 + q];   // may run past the row end: masked below
-#pragma unroll
-                    for (int h = 0; h < 2; ++h) {
-                        const u32 wa = (u32)(xa >> (32 * h)), wb = (u32)(xb >> (32 * h));
-                        const pk_u16 mx = __builtin_elementwise_max(__builtin_bit_cast(pk_u16, wa), __builtin_bit_cast(pk_u16, wb));
-                        const pk_i16 df = __builtin_bit_cast(pk_i16, mx) - __builtin_bit_cast(pk_i16, rr2);
-                        const pk_i16 sg = df >> 15;
-                        const int k = 2 * q + h;                               // vertices 16*c16 + 2k, 2k+1
-                        acc |= __builtin_bit_cast(u32, sg) & ((1u << (2 * k)) | (1u << (2 * k + 17)));
-                    }
+            for (int w = 0; w < NVW; ++w) {
+                const u64 A0 = adj[2 * a + w], B0 = adj[2 * b + w];
+                M0[w] = A0 & B0;
+                M[w] = M0[w];
+                u64 cc = (A0 | adjc[2 * a + w]) & (B0 | adjc[2 * b + w]) & ~M0[w];
+                while (cc) {
+                    const int v0 = 64 * w + __builtin_ctzll(cc); cc &= cc - 1ull;
+                    const bool ok1 = cc != 0ull; const int v1 = ok1 ? 64 * w + __builtin_ctzll(cc) : v0; cc &= cc - 1ull;
+                    const int t0 = tri2(v0), t1 = tri2(v1);
+                    const u32 xa0 = rank[v0 < a ? ta0 + v0 : t0 + a], xb0 = rank[v0 < b ? tb0 + v0 : t0 + b];
+                    const u32 xa1 = rank[v1 < a ? ta0 + v1 : t1 + a], xb1 = rank[v1 < b ? tb0 + v1 : t1 + b];
+                    if ((int)(xa0 > xb0 ? xa0 : xb0) < r) M[w] |= 1ull << (v0 & 63);
+                    if (ok1 && (int)(xa1 > xb1 ? xa1 : xb1) < r) M[w] |= 1ull << (v1 & 63);
                 }
-                const u64 bits16 = (u64)((acc | (acc >> 16)) & 0xffffu);
-                if (NVW == 1) M[0] |= bits16 << (16 * c16);
-                else M[(c16 >> 2) & (NVW - 1)] |= bits16 << (16 * (c16 & 3));
             }
-            // drop the bits of padding vertices >= n
-            if (NVW == 1) { if (n < 64) M[0] &= (1ull << n) - 1ull; }
-            else { if (n < 128) M[NVW - 1] &= (n <= 64) ? 0ull : ((1ull << (n - 64)) - 1ull); if (n < 64) M[0] &= (1ull << n) - 1ull; }
-#pragma unroll
-            for (int w = 0; w < NVW; ++w) M0[w] = adj[2 * a + w] & adj[2 * b + w];
         }
         u64 many = 0;
 #pragma unroll
@@ -392,7 +369,7 @@ __device__ void rips_sweep(int n, int E, int Ev, const u16* rank, int ns, Psi<W,
                 u64 cb = rl64(candv, g);
                 if (!cb) continue;
                 // this group's edges and lengths into registers: the walk below is LDS-free
-                const u32 pkv = ordc[64 * g + lane];
+                const u32 pkv = ord[r0 + 64 * g + lane < E ? r0 + 64 * g + lane : E - 1];
                 const u32 keyv = __float_as_uint(ckey[64 * g + lane]);
                 while (cb) {
                     const int l = __builtin_ctzll(cb);
@@ -472,7 +449,7 @@ __device__ void rips_sweep(int n, int E, int Ev, const u16* rank, int ns, Psi<W,
         int d1 = 0, d2 = 0, q1 = 0, q2 = 0;
         if (apparent) {
             d1 = pair_index(a, vstar); d2 = pair_index(b, vstar);
-            q1 = (int)rank[a * ns + vstar] - r0; q2 = (int)rank[b * ns + vstar] - r0;   // < tid
+            q1 = (int)rank[d1] - r0; q2 = (int)rank[d2] - r0;   // < tid
         }
         bool pending = apparent;
         if (!apparent) done[tid] = 1;       // candidates (and idle lanes) are settled
@@ -722,7 +699,7 @@ __device__ void rips_sweep(int n, int E, int Ev, const u16* rank, int ns, Psi<W,
                             mycode = ((u32)ycw << 8) | (u32)ybit; myrk = (u32)rk; mybirth = ybirth;
                         }
                     } else {
-                        const u32 pkk = ordc[rk - r0];
+                        const u32 pkk = ord[rk];
                         const float key = keyfn(rk, (int)(pkk >> 8), (int)(pkk & 255u));
                         if (key > ybirth) {
                             if (k1 < h1_cap && lane == 0) { h1[2 * k1] = (double)ybirth; h1[2 * k1 + 1] = (double)key; }
@@ -754,7 +731,7 @@ __device__ void rips_sweep(int n, int E, int Ev, const u16* rank, int ns, Psi<W,
                     const bool mine_ok = lane < nk;
                     float key = 0.f;
                     if (mine_ok) {
-                        const u32 pkk = ordc[(int)myrk - r0];
+                        const u32 pkk = ord[(int)myrk];
                         key = keyfn((int)myrk, (int)(pkk >> 8), (int)(pkk & 255u));
                     }
                     const bool emit = mine_ok && key > mybirth;
@@ -870,11 +847,12 @@ __device__ void rips_sweep(int n, int E, int Ev, const u16* rank, int ns, Psi<W,
     out_k0 = k0; out_k1 = k1; out_status = status;
 }
 
-// rank matrix (and skey) from the sorted composites; rank rows pre-filled with RANK_NONE.
-// STAGE: the rank region overlaps the sorted array (psi narrower than 8 B per edge), so every
+// rank (triangular: rank[tri2(a) + b] = position of edge (a,b), a > b; RANK_NONE beyond the effective
+// threshold), ord (ord[e] = a << 8 | b) and, for distance matrices, skey from the sorted composites.
+// STAGE: the rank/ord region overlaps the sorted array (psi narrower than 8 B per edge), so every
 // thread first pulls its <= 16 entries into registers.
 template <int NT, bool WANT_KEYS, bool STAGE>
-__device__ void unpack_sorted(const u64* S, int E, int Ev, int n, u16* rank, int ns, u32* skey)
+__device__ void unpack_sorted(const u64* S, int E, int Ev, u16* rank, u16* ord, u32* skey)
 {
     const int tid = threadIdx.x;
     constexpr int MAXPT = STAGE ? (TDA_MAX_POINTS * (TDA_MAX_POINTS - 1) / 2 + NT - 1) / NT : 1;
@@ -883,19 +861,14 @@ __device__ void unpack_sorted(const u64* S, int E, int Ev, int n, u16* rank, int
 #pragma unroll
         for (int k = 0; k < MAXPT; ++k) { const int e = tid + k * NT; held[k] = e < E ? S[e] : ~0ull; }
         __syncthreads();
-    }
-    for (int i = tid; i < n * ns; i += NT) rank[i] = (u16)RANK_NONE;
-    __syncthreads();
-    if (STAGE) {
 #pragma unroll
         for (int k = 0; k < MAXPT; ++k) {
             const int e = tid + k * NT;
             if (e < E) {
                 const u32 pk = (u32)(held[k] & 0xffffu);
                 const int a = (int)(pk >> 8), b = (int)(pk & 255u);
-                const u16 rr = (e < Ev) ? (u16)e : (u16)RANK_NONE;
-                rank[a * ns + b] = rr;
-                rank[b * ns + a] = rr;
+                rank[tri2(a) + b] = (e < Ev) ? (u16)e : (u16)RANK_NONE;
+                ord[e] = (u16)pk;
             }
         }
     } else {
@@ -904,9 +877,8 @@ __device__ void unpack_sorted(const u64* S, int E, int Ev, int n, u16* rank, int
             const u32 pk = (u32)(c & 0xffffu);
             const int a = (int)(pk >> 8), b = (int)(pk & 255u);
             if (WANT_KEYS) skey[e] = (u32)(c >> 16);
-            const u16 rr = (e < Ev) ? (u16)e : (u16)RANK_NONE;
-            rank[a * ns + b] = rr;
-            rank[b * ns + a] = rr;
+            rank[tri2(a) + b] = (e < Ev) ? (u16)e : (u16)RANK_NONE;
+            ord[e] = (u16)pk;
         }
     }
     __syncthreads();
@@ -931,6 +903,7 @@ __device__ void rips_dm_window(unsigned char* smem, const int win, const double*
     u64* S = reinterpret_cast<u64*>(smem);
     Psi<W, WT>* psi = reinterpret_cast<Psi<W, WT>*>(smem);
     u16* rank = reinterpret_cast<u16*>(smem + L.off_rank);
+    u16* ord = reinterpret_cast<u16*>(smem + L.off_ord);
     u32* skey = reinterpret_cast<u32*>(smem + L.off_aux);
     unsigned char* misc = smem + L.off_misc;
     int* red = reinterpret_cast<int*>(misc + MISC_MIN);
@@ -962,11 +935,11 @@ __device__ void rips_dm_window(unsigned char* smem, const int win, const double*
     PROF_MARK(0);
     bitonic_sort_lds<NT>(S, npad);
     PROF_MARK(1);
-    unpack_sorted<NT, true, false>(S, E, Ev, n, rank, L.rank_stride, skey);
+    unpack_sorted<NT, true, false>(S, E, Ev, rank, ord, skey);
     PROF_MARK(2);
     int k0, k1, st;
     KeyFromLds kf{skey};
-    rips_sweep<NT, NVW, W, WT>(n, E, Ev, rank, L.rank_stride, psi, misc, kf,
+    rips_sweep<NT, NVW, W, WT>(n, E, Ev, rank, ord, psi, misc, kf,
                        out.h0 + (size_t)win * out.h0_cap * 2, out.h0_cap,
                        out.h1 + (size_t)win * out.h1_cap * 2, out.h1_cap, k0, k1, st);
     PROF_MARK(3);
@@ -1028,10 +1001,11 @@ __device__ void rips_cloud_window(unsigned char* smem, const int win, const doub
     u64* S = reinterpret_cast<u64*>(smem);
     Psi<W, WT>* psi = reinterpret_cast<Psi<W, WT>*>(smem);
     u16* rank = reinterpret_cast<u16*>(smem + L.off_rank);
+    u16* ord = reinterpret_cast<u16*>(smem + L.off_ord);
     double* pts = reinterpret_cast<double*>(smem + L.off_aux);
     unsigned char* misc = smem + L.off_misc;
     int* red = reinterpret_cast<int*>(misc + MISC_MIN);
-    double* mm = reinterpret_cast<double*>(misc + MISC_BRANK);   // min/max scratch (before the sweep)
+    double* mm = reinterpret_cast<double*>(misc + MISC_CKEY);    // min/max scratch (before the sweep)
 
     double* h0 = out.h0 + (size_t)win * out.h0_cap * 2;
     double* h1 = out.h1 + (size_t)win * out.h1_cap * 2;
@@ -1113,13 +1087,13 @@ __device__ void rips_cloud_window(unsigned char* smem, const int win, const doub
     PROF_MARK(0);
     bitonic_sort_lds<NT>(S, npad);
     PROF_MARK(1);
-    unpack_sorted<NT, false, (sizeof(WT) < 8)>(S, E, Ev, P, rank, L.rank_stride, nullptr);
+    unpack_sorted<NT, false, (sizeof(WT) < 8)>(S, E, Ev, rank, ord, nullptr);
     PROF_MARK(2);
     int k0, k1, st;
     if (P <= 64)
-        rips_sweep<NT, 1, W, WT>(P, E, Ev, rank, L.rank_stride, psi, misc, kf, h0, out.h0_cap, h1, out.h1_cap, k0, k1, st);
+        rips_sweep<NT, 1, W, WT>(P, E, Ev, rank, ord, psi, misc, kf, h0, out.h0_cap, h1, out.h1_cap, k0, k1, st);
     else
-        rips_sweep<NT, 2, W, WT>(P, E, Ev, rank, L.rank_stride, psi, misc, kf, h0, out.h0_cap, h1, out.h1_cap, k0, k1, st);
+        rips_sweep<NT, 2, W, WT>(P, E, Ev, rank, ord, psi, misc, kf, h0, out.h0_cap, h1, out.h1_cap, k0, k1, st);
     PROF_MARK(3);
     PROF_COUNT(8, 1);
     PROF_COUNT(9, E);
@@ -1176,24 +1150,22 @@ h1_order_kernel(double* __restrict__ h1, int h1_cap, const int* __restrict__ h1_
 // ---------------------------------------------------------------------------------
 static inline int align16(int x) { return (x + 15) & ~15; }
 
-static RipsLayout make_layout(int n, int psi_bytes_per_edge, int aux_bytes, int NT)
+static RipsLayout make_layout(int n, int psi_bytes_per_edge, int aux_bytes, int NT)   // classes = 8 * psi_bytes_per_edge
 {
     RipsLayout L;
     const int E = n * (n - 1) / 2;
     int npad = 2 * NT;
     while (npad < E) npad <<= 1;
     const int psi_bytes = E * psi_bytes_per_edge;
-    // the sort array may run past psi into rank (written only after the sort); it must
+    // the sort array may run past psi into rank / ord (written only after the sort); it must
     // stop before aux (point cloud: read after the sort) and misc
-    int ns = (n + 3) & ~3;
-    if ((ns & 7) == 0) ns += 4;                   // odd multiple of 4: spreads rows over LDS banks
-    L.rank_stride = ns;
     L.off_rank = align16(psi_bytes);
-    int after_rank = align16(L.off_rank + n * ns * 2);
+    L.off_ord = align16(L.off_rank + 2 * E);
+    int after_rank = align16(L.off_ord + 2 * E);
     if (after_rank < npad * 8) after_rank = align16(npad * 8);
     L.off_aux = after_rank;
     L.off_misc = align16(L.off_aux + aux_bytes);
-    L.total = align16(L.off_misc + MISC_BYTES);
+    L.total = align16(L.off_misc + MISC_BYTES(8 * psi_bytes_per_edge));
     return L;
 }
 
