@@ -255,6 +255,19 @@ tda_status tda_event_record(tda_ctx* ctx, void* ev, void* stream);
 tda_status tda_event_elapsed_ms(tda_ctx* ctx, void* ev_start, void* ev_stop, float* ms); /* syncs on stop */
 tda_status tda_event_destroy(tda_ctx* ctx, void* ev);
 tda_status tda_stream_sync(tda_ctx* ctx, void* stream);
+/* Arms a one-shot probe: the NEXT launch of the first-pass kernel of `which` made through this
+ * context records ev_start right before and ev_stop right after that ONE kernel on its stream
+ * (the retry passes and the row-ordering kernel of the same call are outside the bracket).  This is
+ * the per-kernel duration bench.py's roofline uses; rocprofv3 --kernel-trace reports the same kernel.
+ * dev_span (optional, TDA_PROBE_RIPS_CLOUD only): device u64[2] preset to {~0, 0}; the kernel leaves
+ * the 100 MHz wall-clock time of its first workgroup start and last workgroup end there -- the
+ * interval a kernel trace shows, i.e. without the time the grid waits for CU slots behind other
+ * in-flight batches. */
+#define TDA_PROBE_NONE       0
+#define TDA_PROBE_RIPS_CLOUD 1   /* rips_cloud_kernel, first pass (tda_takens_rips_batch / tda_cloud_rips_batch) */
+#define TDA_PROBE_RIPS_DM    2   /* rips_dm_kernel, first pass (tda_rips_dm_batch) */
+#define TDA_PROBE_CORR_DIST  3   /* corr_dist_kernel (tda_corr_dist_batch / _sliding) */
+tda_status tda_set_kernel_probe(tda_ctx* ctx, int which, void* ev_start, void* ev_stop, void* dev_span);
 
 #ifdef __cplusplus
 }

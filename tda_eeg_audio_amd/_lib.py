@@ -72,6 +72,7 @@ SYMBOLS = {
     "tda_event_record": (_I, [c_vp, c_vp, c_vp]),
     "tda_event_elapsed_ms": (_I, [c_vp, c_vp, c_vp, C.POINTER(C.c_float)]),
     "tda_event_destroy": (_I, [c_vp, c_vp]),
+    "tda_set_kernel_probe": (_I, [c_vp, _I, c_vp, c_vp, c_vp]),
     "tda_stream_sync": (_I, [c_vp, c_vp]),
 }
 
@@ -128,6 +129,24 @@ class Context:
 
     def set_class_words(self, words_dm=2, words_cloud=1):
         self.check(self.lib.tda_set_class_words(self.h, words_dm, words_cloud))
+
+    # ---- one-shot kernel probe (bench.py roofline): HIP events around ONE first-pass kernel ----
+    PROBES = {"rips_audio": 1, "rips_eeg": 2, "corr_dist": 3}
+
+    def new_event(self):
+        ev = c_vp()
+        self.check(self.lib.tda_event_create(self.h, C.byref(ev)))
+        return ev
+
+    def arm_probe(self, stage, ev_start, ev_stop, dev_span=None):
+        """dev_span: optional device pointer (int) to u64[2] = {~0, 0} (rips_audio only)."""
+        self.check(self.lib.tda_set_kernel_probe(self.h, self.PROBES[stage], ev_start, ev_stop,
+                                                 c_vp(dev_span) if dev_span else None))
+
+    def elapsed_ms(self, ev_start, ev_stop):
+        ms = C.c_float()
+        self.check(self.lib.tda_event_elapsed_ms(self.h, ev_start, ev_stop, C.byref(ms)))
+        return float(ms.value)
 
     def close(self):
         if getattr(self, "h", None):

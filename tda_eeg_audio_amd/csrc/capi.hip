@@ -589,6 +589,17 @@ tda_status tda_event_destroy(tda_ctx* ctx, void* ev)
     if (ev) TDA_HIP(ctx, hipEventDestroy((hipEvent_t)ev));
     return TDA_OK;
 }
+tda_status tda_set_kernel_probe(tda_ctx* ctx, int which, void* ev_start, void* ev_stop, void* dev_span)
+{
+    CHECK_CTX(ctx);
+    if (which < TDA_PROBE_NONE || which > TDA_PROBE_CORR_DIST) TDA_FAIL(ctx, TDA_ERR_INVALID, "unknown probe");
+    if (which != TDA_PROBE_NONE && (!ev_start || !ev_stop)) TDA_FAIL(ctx, TDA_ERR_INVALID, "probe needs two events");
+    ctx->probe_which = which;
+    ctx->probe_start = (hipEvent_t)ev_start;
+    ctx->probe_stop = (hipEvent_t)ev_stop;
+    ctx->probe_span = (unsigned long long*)dev_span;
+    return TDA_OK;
+}
 tda_status tda_stream_sync(tda_ctx* ctx, void* stream)
 {
     CHECK_CTX(ctx);

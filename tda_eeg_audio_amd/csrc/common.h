@@ -17,6 +17,27 @@ struct tda_ctx {
     void* ws = nullptr;
     size_t ws_bytes = 0;
     std::string err;
+    // one-shot kernel probe (tda_set_kernel_probe)
+    int probe_which = 0;
+    hipEvent_t probe_start = nullptr, probe_stop = nullptr;
+    unsigned long long* probe_span = nullptr;   // device u64[2] {~0, 0}: first workgroup start / last workgroup end
+};
+
+// brackets ONE kernel launch with the armed probe events (if `which` is armed)
+struct ProbeScope {
+    tda_ctx* ctx; hipStream_t st; bool on; unsigned long long* span;
+    ProbeScope(tda_ctx* c, int which, hipStream_t s)
+        : ctx(c), st(s), on(c->probe_which == which && c->probe_start && c->probe_stop), span(c->probe_span)
+    {
+        if (on) (void)hipEventRecord(ctx->probe_start, st);
+    }
+    ~ProbeScope()
+    {
+        if (on) {
+            (void)hipEventRecord(ctx->probe_stop, st);
+            ctx->probe_which = 0; ctx->probe_start = ctx->probe_stop = nullptr; ctx->probe_span = nullptr;
+        }
+    }
 };
 
 #define TDA_HIP(ctx, call)                                                          \

@@ -341,6 +341,7 @@ static tda_status cd_launch_nb(tda_ctx* ctx, const double* win, int n_win, int n
 {
     constexpr int CP = 16 * NB;
     const size_t lds = sizeof(double) * ((size_t)CD_TCH * (CP + 1) + (size_t)(NB * (NB + 1) / 2) * 256 + 2 * (size_t)CP);
+    ProbeScope probe(ctx, TDA_PROBE_CORR_DIST, st);
     if (n_t <= CD_RES_CHUNKS * CD_TCH)
         hipLaunchKernelGGL((corr_dist_kernel<NB, true>), dim3(n_win), dim3(256), lds, st, win, n_win, n_ch, n_t, win_stride,
                            ld, dist, corr);

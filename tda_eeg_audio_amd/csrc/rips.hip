@@ -1104,15 +1104,20 @@ template <int NT, int W, typename WT>
 __global__ void __launch_bounds__(NT)
 rips_cloud_kernel(const double* __restrict__ src, const int* __restrict__ tau_or_npts, int n_win,
                   int n_t_or_pcap, int dim, int subsample, int mode, int normalise, float thresh,
-                  RipsLayout L, int p_max, int* __restrict__ n_points, RipsOut out, int retry_only)
+                  RipsLayout L, int p_max, int* __restrict__ n_points, RipsOut out, int retry_only,
+                  unsigned long long* __restrict__ span)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    // armed probe only: span[0] = earliest workgroup start, span[1] = latest workgroup end (100 MHz wall clock),
+    // i.e. the interval a kernel trace reports for this launch
+    if (span && threadIdx.x == 0) atomicMin(&span[0], wall_clock64());
     for (int win = blockIdx.x; win < n_win; win += gridDim.x) {
         if (retry_only && !(out.status[win] & TDA_WIN_CLASS_OVERFLOW)) continue;   // workgroup-uniform
         rips_cloud_window<NT, W, WT>(smem, win, src, tau_or_npts, n_t_or_pcap, dim, subsample, mode, normalise,
                                      thresh, L, p_max, n_points, out);
         __syncthreads();
     }
+    if (span && threadIdx.x == 0) atomicMax(&span[1], wall_clock64());
 }
 
 // ---------------------------------------------------------------------------------
@@ -1189,9 +1194,15 @@ static tda_status launch_dm_t(tda_ctx* ctx, const double* dm, int n_win, int n, 
     if (L.total > 48 * 1024)
         TDA_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, L.total));
-    const int grid = retry_only ? (n_win < 64 ? n_win : 64) : n_win;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(NT), L.total, st, dm, n_win, n, thresh, symmetrise, L, out,
-                       retry_only);
+    // retry passes walk the status array on a small strided grid; the widest variant (240 VGPRs, > 80 KB LDS)
+    // needs a nearly empty CU per workgroup, so it asks for few of them
+    const int rgrid = W >= 8 ? 16 : 64;
+    const int grid = retry_only ? (n_win < rgrid ? n_win : rgrid) : n_win;
+    {
+        ProbeScope probe(ctx, retry_only ? -1 : TDA_PROBE_RIPS_DM, st);
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(NT), L.total, st, dm, n_win, n, thresh, symmetrise, L, out,
+                           retry_only);
+    }
     TDA_HIP(ctx, hipGetLastError());
     return TDA_OK;
 }
@@ -1250,8 +1261,11 @@ static tda_status launch_cloud_t(tda_ctx* ctx, const double* src, const int* aux
         TDA_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, L.total));
     const int grid = retry_only ? (n_win < 64 ? n_win : 64) : n_win;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(NT), L.total, st, src, aux, n_win, n_t_or_pcap, dim, subsample, mode,
-                       normalise, thresh, L, p_max, n_points, out, retry_only);
+    {
+        ProbeScope probe(ctx, retry_only ? -1 : TDA_PROBE_RIPS_CLOUD, st);
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(NT), L.total, st, src, aux, n_win, n_t_or_pcap, dim, subsample, mode,
+                           normalise, thresh, L, p_max, n_points, out, retry_only, probe.on ? probe.span : nullptr);
+    }
     TDA_HIP(ctx, hipGetLastError());
     return TDA_OK;
 }
