@@ -361,35 +361,72 @@ __device__ void rips_sweep(int n, int E, int Ev, const u16* rank, const u16* ord
         if (is_cand) ckey[tid] = keyfn(r, a, b);     // every candidate needs its length (H0 death / H1 birth)
         done[tid] = 0;
         __syncthreads();
+        PROF_MARK(21);
         // wave 0 alone walks the candidates in rank order (the other waves would only replay the
         // same scalar work and fight for issue slots); LDS accesses of one wave are in order
         if (wave == 0) {
             const u64 candv = cand[lane & (NT / 64 - 1)];     // all ballots in one LDS read
+            // The walk is one dependent chain, so it is kept free of memory operations and almost free of
+            // branches: H0 rows and births are parked in lanes (row j / birth j of the current batch in
+            // lane j) and written out 64 at a time; the label update is unconditional (a no-op when both
+            // ends already carry the same label).
+            float hkey = 0.f;                     // parked H0 deaths
+            int hn = 0, hbase = k0;
+            u32 b_tab = 0u, b_idx = 0u, b_rq = 0u;    // parked births: psi slot, class index (word * WB + bit), rank
+            float b_key = 0.f;
+            int bn = 0;
+            auto flush_rows = [&]() {
+                const int pos = hbase + lane;
+                if (lane < hn && pos < h0_cap) { h0[2 * pos] = 0.0; h0[2 * pos + 1] = (double)hkey; }
+                hbase += hn; hn = 0;
+            };
+            auto flush_births = [&]() {
+                if (lane < bn) {
+                    Psi<W, WT> nv = pzero<W, WT>();
+                    const int cw = (int)b_idx / WB, bit = (int)b_idx & (WB - 1);
+#pragma unroll
+                    for (int c = 0; c < W; ++c)
+                        if (c == cw) nv.w[c] = ((WT)1 << bit);
+                    psi[b_tab] = nv;
+                    brank[b_idx] = (int)b_rq;
+                    bkey[b_idx] = b_key;
+                }
+                bn = 0;
+            };
             for (int g = 0; g < NT / 64 && !status && clen == NT; ++g) {
                 u64 cb = rl64(candv, g);
                 if (!cb) continue;
-                // this group's edges and lengths into registers: the walk below is LDS-free
+                PROF_COUNT(20, __builtin_popcountll(cb));
+                // this group's edges and lengths into registers
                 const u32 pkv = ord[r0 + 64 * g + lane < E ? r0 + 64 * g + lane : E - 1];
                 const u32 keyv = __float_as_uint(ckey[64 * g + lane]);
                 while (cb) {
                     const int l = __builtin_ctzll(cb);
                     cb &= cb - 1;
                     const int q = 64 * g + l;
-                    const int rq = r0 + q;
                     const u32 pk = rl32(pkv, l);
-                    const float key = __uint_as_float(rl32(keyv, l));
+                    const u32 keyb = rl32(keyv, l);
                     const int qa = (int)(pk >> 8), qb = (int)(pk & 255u);
-                    const int ca = qa < 64 ? (int)rl32((u32)compA, qa) : (int)rl32((u32)compB, qa - 64);
-                    const int cbb = qb < 64 ? (int)rl32((u32)compA, qb) : (int)rl32((u32)compB, qb - 64);
-                    if (ca != cbb) {
-                        compA = compA == cbb ? ca : compA;
-                        compB = compB == cbb ? ca : compB;
-                        ++merges;
-                        if (key != 0.0f) {
-                            if (k0 < h0_cap && lane == 0) { h0[2 * k0] = 0.0; h0[2 * k0 + 1] = (double)key; }
-                            ++k0;
-                        }
+                    int ca, cbb;
+                    if (NVW == 1) {
+                        ca = (int)rl32((u32)compA, qa);
+                        cbb = (int)rl32((u32)compA, qb);
                     } else {
+                        const int a0 = (int)rl32((u32)compA, qa & 63), a1 = (int)rl32((u32)compB, qa & 63);
+                        const int b0 = (int)rl32((u32)compA, qb & 63), b1 = (int)rl32((u32)compB, qb & 63);
+                        ca = qa < 64 ? a0 : a1;
+                        cbb = qb < 64 ? b0 : b1;
+                    }
+                    const bool mrg = ca != cbb;
+                    compA = compA == cbb ? ca : compA;
+                    if (NVW == 2) compB = compB == cbb ? ca : compB;
+                    merges += mrg ? 1 : 0;
+                    const bool row = mrg && keyb != 0u && keyb != 0x80000000u;       // zero-length edges give no row
+                    hkey = (row && lane == hn) ? __uint_as_float(keyb) : hkey;
+                    hn += row ? 1 : 0;
+                    k0 += row ? 1 : 0;
+                    if (hn == 64) flush_rows();
+                    if (!mrg) {
                         int cw = -1, bit = 0;
 #pragma unroll
                         for (int c = W - 1; c >= 0; --c) {
@@ -406,18 +443,18 @@ __device__ void rips_sweep(int n, int E, int Ev, const u16* rank, const u16* ord
 #pragma unroll
                         for (int c = 0; c < W; ++c)
                             if (c == cw) alive[c] |= ((WT)1 << bit);
-                        if (lane == 0) {
-                            Psi<W, WT> nv = pzero<W, WT>();
-#pragma unroll
-                            for (int c = 0; c < W; ++c)
-                                if (c == cw) nv.w[c] = ((WT)1 << bit);
-                            psi[tri2(qa) + qb] = nv;
-                            brank[WB * cw + bit] = rq;
-                            bkey[WB * cw + bit] = key;
-                        }
+                        const bool me = lane == bn;
+                        b_tab = me ? (u32)(tri2(qa) + qb) : b_tab;
+                        b_idx = me ? (u32)(WB * cw + bit) : b_idx;
+                        b_rq = me ? (u32)(r0 + q) : b_rq;
+                        b_key = me ? __uint_as_float(keyb) : b_key;
+                        if (++bn == 64) flush_births();
                     }
                 }
             }
+            flush_rows();
+            flush_births();
+            PROF_MARK(22);
             if (lane == 0) {
 #pragma unroll
                 for (int c = 0; c < W; ++c) shared->alive[c] = (u64)alive[c];
