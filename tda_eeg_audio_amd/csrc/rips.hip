@@ -286,7 +286,6 @@ __device__ void rips_sweep(int n, int E, int Ev, const u16* rank, const u16* ord
     int* brank = reinterpret_cast<int*>(misc + MISC_BRANK);
     u64* cand = reinterpret_cast<u64*>(misc + MISC_CAND);
     unsigned char* done = misc + MISC_DONE;
-    float* ckey = reinterpret_cast<float*>(misc + MISC_CKEY);
     SweepShared* shared = reinterpret_cast<SweepShared*>(misc + MISC_SHARED);
     u64* adj = reinterpret_cast<u64*>(misc + MISC_ADJ);      // adj[2*v + w]: neighbours of v among vertices 64w..64w+63
     constexpr int WB = 8 * (int)sizeof(WT);          // class bits per word
@@ -309,6 +308,7 @@ __device__ void rips_sweep(int n, int E, int Ev, const u16* rank, const u16* ord
     for (int r0 = 0; r0 < Ev && !status; r0 += clen) {
         clen = NT;
         PROF_MARK(15);
+        PROF_COUNT(23, 1);
         if (tid < 256) adjc[tid] = 0ull;
         __syncthreads();
         const int r = r0 + tid;
@@ -353,118 +353,147 @@ __device__ void rips_sweep(int n, int E, int Ev, const u16* rank, const u16* ord
         for (int w = 0; w < NVW; ++w) many |= M[w];
         const bool is_cand = valid && many == 0;
         PROF_MARK(4);
-        // ---- b. candidates: sequential union-find in rank order (workgroup-uniform loop) ----
+        // ---- b. candidates (edges without a common neighbour): Kruskal in rank order ----
+        // Only the union-find itself is sequential: wave 0 walks the candidates with the component labels
+        // in registers and leaves one "merge" bit per edge.  Everything that follows from the decision
+        // -- H0 rows, class bits of the births, psi/brank/bkey entries, counters -- is allocated by
+        // prefix sums over ballots and written by the lanes that own the edges.
+        u64* mbal = reinterpret_cast<u64*>(misc + MISC_COMP);        // [8] merge bits per wave of edges
+        u64* zbal = mbal + 8;                                        // [8] candidates of length zero (no H0 row)
+        int* offs = reinterpret_cast<int*>(mbal + 16);               // [8] births, [8] rows before each wave, totals, clen
+        u16* freebits = reinterpret_cast<u16*>(misc + MISC_CKEY);    // j-th free class index
+        float mykey = 0.f;
+        if (is_cand) mykey = keyfn(r, a, b);         // every candidate needs its length (H0 death / H1 birth)
         {
-            const u64 bal = __ballot(is_cand);
-            if (lane == 0) cand[wave] = bal;
+            const u64 bal = __ballot(is_cand), zb = __ballot(is_cand && mykey == 0.0f);
+            if (lane == 0) { cand[wave] = bal; zbal[wave] = zb; }
         }
-        if (is_cand) ckey[tid] = keyfn(r, a, b);     // every candidate needs its length (H0 death / H1 birth)
         done[tid] = 0;
         __syncthreads();
         PROF_MARK(21);
-        // wave 0 alone walks the candidates in rank order (the other waves would only replay the
-        // same scalar work and fight for issue slots); LDS accesses of one wave are in order
+        int nfree = 0;
+#pragma unroll
+        for (int c = 0; c < W; ++c) nfree += __builtin_popcountll((u64)(WT)~alive[c]);
         if (wave == 0) {
+            // The walk stops at the first birth that finds no free class bit: the chunk is closed just before
+            // that edge, so that the kills of the shortened chunk can free bits (capacity = classes alive at
+            // once).  q = NT: the whole chunk went through.
             const u64 candv = cand[lane & (NT / 64 - 1)];     // all ballots in one LDS read
-            // The walk is one dependent chain, so it is kept free of memory operations and almost free of
-            // branches: H0 rows and births are parked in lanes (row j / birth j of the current batch in
-            // lane j) and written out 64 at a time; the label update is unconditional (a no-op when both
-            // ends already carry the same label).
-            float hkey = 0.f;                     // parked H0 deaths
-            int hn = 0, hbase = k0;
-            u32 b_tab = 0u, b_idx = 0u, b_rq = 0u;    // parked births: psi slot, class index (word * WB + bit), rank
-            float b_key = 0.f;
-            int bn = 0;
-            auto flush_rows = [&]() {
-                const int pos = hbase + lane;
-                if (lane < hn && pos < h0_cap) { h0[2 * pos] = 0.0; h0[2 * pos + 1] = (double)hkey; }
-                hbase += hn; hn = 0;
-            };
-            auto flush_births = [&]() {
-                if (lane < bn) {
-                    Psi<W, WT> nv = pzero<W, WT>();
-                    const int cw = (int)b_idx / WB, bit = (int)b_idx & (WB - 1);
-#pragma unroll
-                    for (int c = 0; c < W; ++c)
-                        if (c == cw) nv.w[c] = ((WT)1 << bit);
-                    psi[b_tab] = nv;
-                    brank[b_idx] = (int)b_rq;
-                    bkey[b_idx] = b_key;
-                }
-                bn = 0;
-            };
-            for (int g = 0; g < NT / 64 && !status && clen == NT; ++g) {
-                u64 cb = rl64(candv, g);
-                if (!cb) continue;
-                PROF_COUNT(20, __builtin_popcountll(cb));
-                // this group's edges and lengths into registers
-                const u32 pkv = ord[r0 + 64 * g + lane < E ? r0 + 64 * g + lane : E - 1];
-                const u32 keyv = __float_as_uint(ckey[64 * g + lane]);
-                while (cb) {
-                    const int l = __builtin_ctzll(cb);
-                    cb &= cb - 1;
-                    const int q = 64 * g + l;
-                    const u32 pk = rl32(pkv, l);
-                    const u32 keyb = rl32(keyv, l);
-                    const int qa = (int)(pk >> 8), qb = (int)(pk & 255u);
-                    int ca, cbb;
-                    if (NVW == 1) {
-                        ca = (int)rl32((u32)compA, qa);
-                        cbb = (int)rl32((u32)compA, qb);
-                    } else {
-                        const int a0 = (int)rl32((u32)compA, qa & 63), a1 = (int)rl32((u32)compB, qa & 63);
-                        const int b0 = (int)rl32((u32)compA, qb & 63), b1 = (int)rl32((u32)compB, qb & 63);
-                        ca = qa < 64 ? a0 : a1;
-                        cbb = qb < 64 ? b0 : b1;
-                    }
-                    const bool mrg = ca != cbb;
-                    compA = compA == cbb ? ca : compA;
-                    if (NVW == 2) compB = compB == cbb ? ca : compB;
-                    merges += mrg ? 1 : 0;
-                    const bool row = mrg && keyb != 0u && keyb != 0x80000000u;       // zero-length edges give no row
-                    hkey = (row && lane == hn) ? __uint_as_float(keyb) : hkey;
-                    hn += row ? 1 : 0;
-                    k0 += row ? 1 : 0;
-                    if (hn == 64) flush_rows();
-                    if (!mrg) {
-                        int cw = -1, bit = 0;
-#pragma unroll
-                        for (int c = W - 1; c >= 0; --c) {
-                            const WT fr = (WT)~alive[c];
-                            if (fr) { cw = c; bit = __builtin_ctzll((u64)fr); }
+            int q = NT, births = 0;
+            for (int g = 0; g < NT / 64; ++g) {
+                u64 cb = q == NT ? rl64(candv, g) : 0ull;
+                u64 mm = 0ull;
+                if (cb) {
+                    PROF_COUNT(20, __builtin_popcountll(cb));
+                    const u32 pkv = ord[r0 + 64 * g + lane < E ? r0 + 64 * g + lane : E - 1];
+                    while (cb) {
+                        const int l = __builtin_ctzll(cb);
+                        cb &= cb - 1;
+                        const u32 pk = rl32(pkv, l);
+                        const int qa = (int)(pk >> 8), qb = (int)(pk & 255u);
+                        int ca, cbb;
+                        if (NVW == 1) {
+                            ca = (int)rl32((u32)compA, qa);
+                            cbb = (int)rl32((u32)compA, qb);
+                        } else {
+                            const int a0 = (int)rl32((u32)compA, qa & 63), a1 = (int)rl32((u32)compB, qa & 63);
+                            const int b0 = (int)rl32((u32)compA, qb & 63), b1 = (int)rl32((u32)compB, qb & 63);
+                            ca = qa < 64 ? a0 : a1;
+                            cbb = qb < 64 ? b0 : b1;
                         }
-                        if (cw < 0) {
-                            // every class bit is in use: close the chunk just before this edge so that the
-                            // kills of the shortened chunk can free bits (capacity = classes alive at once)
-                            if (q == 0) status |= TDA_WIN_CLASS_OVERFLOW;
-                            else clen = q;
-                            break;
-                        }
-#pragma unroll
-                        for (int c = 0; c < W; ++c)
-                            if (c == cw) alive[c] |= ((WT)1 << bit);
-                        const bool me = lane == bn;
-                        b_tab = me ? (u32)(tri2(qa) + qb) : b_tab;
-                        b_idx = me ? (u32)(WB * cw + bit) : b_idx;
-                        b_rq = me ? (u32)(r0 + q) : b_rq;
-                        b_key = me ? __uint_as_float(keyb) : b_key;
-                        if (++bn == 64) flush_births();
+                        // branch-free: once q is set the remaining edges of the group change nothing
+                        const bool same = ca == cbb, open = q == NT;
+                        q = (open && same && births == nfree) ? 64 * g + l : q;
+                        births += same ? 1 : 0;
+                        // relabel the component of b (a no-op when both ends carry the same label already)
+                        const int cnew = (q == NT) ? ca : cbb;
+                        compA = compA == cbb ? cnew : compA;
+                        if (NVW == 2) compB = compB == cbb ? cnew : compB;
+                        mm |= (!same && q == NT) ? (1ull << l) : 0ull;
                     }
                 }
+                if (lane == 0) mbal[g] = mm;
             }
-            flush_rows();
-            flush_births();
-            PROF_MARK(22);
-            if (lane == 0) {
+            // births / rows before each wave of edges and the totals (lane g looks at group g)
+            int nb = 0, nr = 0, nm = 0;
+            if (lane < NT / 64) {
+                u64 cg = cand[lane];
+                if (64 * lane >= q) cg = 0ull;
+                else if (q < 64 * lane + 64) cg &= (1ull << (q - 64 * lane)) - 1ull;
+                const u64 mg = mbal[lane], zg = zbal[lane];
+                nb = __builtin_popcountll(cg & ~mg); nr = __builtin_popcountll(mg & ~zg); nm = __builtin_popcountll(mg);
+            }
+            int pb = 0, pr = 0, tb = 0, tr = 0, tm = 0;
 #pragma unroll
-                for (int c = 0; c < W; ++c) shared->alive[c] = (u64)alive[c];
-                shared->k0 = k0; shared->merges = merges; shared->status = status; shared->clen = clen;
+            for (int w = 0; w < NT / 64; ++w) {
+                const int xb = (int)rl32((u32)nb, w), xr = (int)rl32((u32)nr, w), xm = (int)rl32((u32)nm, w);
+                if (w < lane) { pb += xb; pr += xr; }
+                tb += xb; tr += xr; tm += xm;
+            }
+            if (lane < NT / 64) { offs[lane] = pb; offs[8 + lane] = pr; }
+            if (lane == 0) { offs[16] = tb; offs[17] = tr; offs[18] = tm; offs[19] = q; }
+        } else {
+            // meanwhile: the j-th free class index (every class looks up its own rank among the free ones)
+            for (int t = tid - 64; t < WB * W; t += NT - 64) {
+                const int cw = t / WB, bit = t & (WB - 1);
+                int rk = 0;
+                bool fr = false;
+#pragma unroll
+                for (int c = 0; c < W; ++c) {
+                    const WT f_ = (WT)~alive[c];
+                    if (c < cw) rk += __builtin_popcountll((u64)f_);
+                    if (c == cw) { rk += __builtin_popcountll((u64)(f_ & (((WT)1 << bit) - (WT)1))); fr = (f_ >> bit) & (WT)1; }
+                }
+                if (fr) freebits[rk] = (u16)t;
             }
         }
         __syncthreads();
+        PROF_MARK(22);
+        clen = offs[19];
+        if (clen == 0) status |= TDA_WIN_CLASS_OVERFLOW;      // not even the first edge of the chunk fits
+        if (clen < NT) PROF_COUNT(14, 1);
+        bool mrg = is_cand && ((mbal[wave] >> lane) & 1ull);
+        bool birth = is_cand && !mrg && tid < clen;
+        bool row = mrg && mykey != 0.0f;                           // zero-length edges give no row
+        const u64 below = (1ull << lane) - 1ull;
+        const int bpre = offs[wave] + __builtin_popcountll(__ballot(birth) & below);
+        const int rpre = offs[8 + wave] + __builtin_popcountll(__ballot(row) & below);
+        const int btot = offs[16], rtot = offs[17], mtot = offs[18];
+        if (!status) {
+            if (row) {
+                const int pos = k0 + rpre;
+                if (pos < h0_cap) { h0[2 * pos] = 0.0; h0[2 * pos + 1] = (double)mykey; }
+            }
+            k0 += rtot; merges += mtot;
+            if (birth) {
+                const int idx = (int)freebits[bpre];
+                const int cw = idx / WB, bit = idx & (WB - 1);
+                Psi<W, WT> nv = pzero<W, WT>();
 #pragma unroll
-        for (int c = 0; c < W; ++c) alive[c] = (WT)shared->alive[c];
-        k0 = shared->k0; merges = shared->merges; status = shared->status; clen = shared->clen;
+                for (int c = 0; c < W; ++c)
+                    if (c == cw) nv.w[c] = ((WT)1 << bit);
+                psi[tab] = nv;
+                brank[idx] = r;
+                bkey[idx] = mykey;
+            }
+            // the btot lowest free class indices are in use now (every thread updates its copy)
+            int left = btot;
+#pragma unroll
+            for (int c = 0; c < W; ++c) {
+                const u64 f_ = (u64)(WT)~alive[c];
+                const int pc = __builtin_popcountll(f_);
+                if (left >= pc) { alive[c] = (WT)~(WT)0; left -= pc; }
+                else if (left > 0) {
+                    int lo = 0, hi = 63;                   // smallest p with `left` free bits at positions <= p
+                    while (lo < hi) {
+                        const int mid = (lo + hi) >> 1;
+                        if (__builtin_popcountll(f_ & ((2ull << mid) - 1ull)) >= left) hi = mid; else lo = mid + 1;
+                    }
+                    alive[c] |= (WT)(f_ & ((2ull << lo) - 1ull));
+                    left = 0;
+                }
+            }
+        }
         if (status) break;
         PROF_MARK(5);
         // ---- c. apparent edges: psi[e] = psi[a,v*] ^ psi[b,v*] ----
@@ -1015,8 +1044,9 @@ struct KeyFromPts {
 // class vector) run a small grid that strides over the windows and only redoes the ones the previous
 // pass flagged, so a retry with nothing to do costs a few microseconds instead of n_win LDS-heavy
 // workgroup launches.
+// 128 classes or fewer: four 256-thread workgroups per CU = 4 waves per SIMD (128 VGPRs)
 template <int NT, int NVW, int W, typename WT>
-__global__ void __launch_bounds__(NT)
+__global__ void __launch_bounds__(NT, W <= 2 ? 4 : 1)
 rips_dm_kernel(const double* __restrict__ dm, int n_win, int n, float thresh, int symmetrise, RipsLayout L,
                RipsOut out, int retry_only)
 {
@@ -1137,8 +1167,9 @@ __device__ void rips_cloud_window(unsigned char* smem, const int win, const doub
     if (tid == 0) { out.h0_cnt[win] = k0; out.h1_cnt[win] = k1; out.status[win] = st; }
 }
 
+// two 512-thread workgroups per CU = 4 waves per SIMD (second launch-bound parameter of hip-clang): 128 VGPRs
 template <int NT, int W, typename WT>
-__global__ void __launch_bounds__(NT)
+__global__ void __launch_bounds__(NT, 4)
 rips_cloud_kernel(const double* __restrict__ src, const int* __restrict__ tau_or_npts, int n_win,
                   int n_t_or_pcap, int dim, int subsample, int mode, int normalise, float thresh,
                   RipsLayout L, int p_max, int* __restrict__ n_points, RipsOut out, int retry_only,
