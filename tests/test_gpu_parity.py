@@ -404,3 +404,38 @@ def test_end_to_end_h0_h1_wasserstein_on_pipeline_diagrams(ctx):
         r0 = brute.safe_wasserstein_oracle(e0[w, :ec0[w]], a0[w, :ac0[w]])
         r1 = brute.safe_wasserstein_oracle(e1[w, :ec1[w]], a1[w, :ac1[w]])
         assert abs(w0[w] - r0) < 1e-6 and abs(w1[w] - r1) < 1e-6, (w, w0[w], r0, w1[w], r1)
+
+
+# ------------------------------------------------------------------ whole step, batches in flight
+def test_pipeline_step_vs_oracle_and_lanes(ctx):
+    """pipeline.run_step (cmp:77-122 batched) against the CPU restatement of the same unit, and
+    pipeline.Lanes: five different batches through three lanes give bit-identical rows to the same
+    batches run one after the other (no buffer of a lane is shared or reused too early)."""
+    import torch
+    from oracle import pipeline_ref
+    from tda_eeg_audio_amd import pipeline
+    dev = torch.device("cuda", 0)
+    n_win, wpr = 45, 15
+    seg_off = np.array([0, 15, 30, 45], np.int32)
+    batches = []
+    for k in range(5):
+        eeg = synth.eeg_windows(n_win, seed=500 + k, windows_per_recording=wpr)
+        aud = synth.audio_windows(n_win, ["beta", "alpha", "delta", "theta", "gamma"][k], seed=600 + k)
+        batches.append((eeg, aud, torch.from_numpy(eeg).to(dev), torch.from_numpy(aud).to(dev)))
+    ws = pipeline.Workspace(n_win, seg_off, dev)
+    serial = []
+    for eeg, aud, eeg_t, aud_t in batches:
+        res = pipeline.run_step(eeg_t, aud_t, ws, ctx=ctx)
+        torch.cuda.synchronize()
+        assert int(ws.eeg.status.max()) == 0 and int((ws.aud.status & ~4).max()) == 0
+        serial.append(res.cpu().numpy().copy())
+    ref = pipeline_ref.reference_step_cpu(batches[0][0], batches[0][1], seg_off)
+    assert np.abs(serial[0][:, :2] - ref[:, :2]).max() < 1e-6          # Wasserstein means (north_star bar)
+    assert np.array_equal(serial[0][:, 2:4], ref[:, 2:4])              # tau, window counts
+    assert np.allclose(serial[0][:, 4:], ref[:, 4:], rtol=1e-9, atol=1e-12)
+    lanes = pipeline.Lanes(3, n_win, seg_off, dev)
+    got = [lanes.submit(eeg_t, aud_t, ctx=ctx, post=lambda r: r.clone()) for _, _, eeg_t, aud_t in batches]
+    lanes.drain()
+    torch.cuda.synchronize()
+    for k in range(5):
+        assert np.array_equal(got[k].cpu().numpy(), serial[k], equal_nan=True), k
