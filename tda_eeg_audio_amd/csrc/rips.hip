@@ -294,7 +294,11 @@ __device__ void rips_sweep(int n, int E, int Ev, const u16* rank, const u16* ord
 
     for (int e = tid; e < E; e += NT) psi[e] = pzero<W, WT>();
     for (int i = tid; i < WB * W; i += NT) { brank[i] = -1; bkey[i] = 0.f; }
-    for (int i = tid; i < 256; i += NT) adj[i] = 0ull;
+    for (int i = tid; i < 256; i += NT) { adj[i] = 0ull; adjc[i] = 0ull; }
+    if (tid == 0) {
+        u32* lc = reinterpret_cast<u32*>(misc + MISC_MIN);     // list header: [0] entries, [1] earliest key
+        lc[0] = 0u; lc[1] = 0xffffffffu;
+    }
     __syncthreads();
 
     WT alive[W];
@@ -309,9 +313,7 @@ __device__ void rips_sweep(int n, int E, int Ev, const u16* rank, const u16* ord
         clen = NT;
         PROF_MARK(15);
         PROF_COUNT(23, 1);
-        if (tid < 256) adjc[tid] = 0ull;
-        __syncthreads();
-        const int r = r0 + tid;
+        const int r = r0 + tid;                      // (adjc was cleared at the end of the previous chunk)
         const bool valid = r < Ev;
         int a = 1, b = 0;
         if (valid) { const u32 pk = ord[r]; a = (int)(pk >> 8); b = (int)(pk & 255u); }     // ord[r] = (a << 8 | b), a > b
@@ -621,8 +623,10 @@ __device__ void rips_sweep(int n, int E, int Ev, const u16* rank, const u16* ord
         const u32 mws[4] = {m0, m1, m2, m3};
         int list_rounds = 0;
         while (true) {
-            if (tid == 0) { lcnt[0] = 0u; lcnt[1] = 0xffffffffu; }
-            __syncthreads();
+            if (list_rounds > 0) {                     // the first listing finds the header reset (chunk end)
+                if (tid == 0) { lcnt[0] = 0u; lcnt[1] = 0xffffffffu; }
+                __syncthreads();
+            }
             u32 firstkey = 0xffffffffu;
             Psi<W, WT> firsty = pzero<W, WT>();
             if (apparent) {
@@ -885,11 +889,14 @@ __device__ void rips_sweep(int n, int E, int Ev, const u16* rank, const u16* ord
             if (++list_rounds > 4 * NT) { status |= TDA_WIN_CLASS_OVERFLOW; break; }   // every round kills >= 1 class: never reached
             __syncthreads();            // table rewritten before the chunk is listed again
         }
-        // the chunk's edges join the adjacency rows
+        // the chunk's edges join the adjacency rows; the rows of the chunk's own edges (last read in phase a)
+        // and the list header are reset for the next chunk under the same barrier
         if (valid && tid < clen) {
             atomicOr(reinterpret_cast<unsigned long long*>(&adj[2 * a + (b >> 6)]), 1ull << (b & 63));
             atomicOr(reinterpret_cast<unsigned long long*>(&adj[2 * b + (a >> 6)]), 1ull << (a & 63));
         }
+        if (tid < 256) adjc[tid] = 0ull;
+        if (tid == 0) { lcnt[0] = 0u; lcnt[1] = 0xffffffffu; }
         __syncthreads();
         PROF_MARK(7);
     }

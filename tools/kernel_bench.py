@@ -45,5 +45,33 @@ def main():
         print(f"corr_dist_sliding  n_win={n}  {ms:.4f} ms  {ms * 1e3 / n:.4f} us/window  {gb / ms * 1e3:.1f} GB/s algorithmic")
 
 
-if __name__ == "__main__":
+if __name__ == "__main__" and not (len(sys.argv) > 1 and sys.argv[1] == "audio"):
     main()
+
+
+def audio_only(n=710, lanes=3, steps=60):
+    """Upper bound probe: only the audio Rips stage, `lanes` batches in flight."""
+    import numpy as np
+    from tda_eeg_audio_amd import synth
+    aud = torch.from_numpy(synth.audio_windows(n, "beta", seed=4242)).cuda()
+    tau = torch.full((n,), 3, dtype=torch.int32, device="cuda")
+    outs = [engine.DeviceDiagrams(n, 128, engine.DEFAULT_H1_CAP, aud.device) for _ in range(lanes)]
+    streams = [torch.cuda.Stream() for _ in range(lanes)]
+    def run(k):
+        with torch.cuda.stream(streams[k % lanes]):
+            engine.takens_rips_dev(aud, tau, outs[k % lanes])
+    for k in range(6):
+        run(k)
+    torch.cuda.synchronize()
+    import time
+    t0 = time.perf_counter()
+    for k in range(steps):
+        run(k)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    print(f"audio Rips only: n={n} lanes={lanes}: {dt * 1e3:.4f} ms per batch -> {n / dt:.0f} windows/s")
+
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "audio":
+    for L in (1, 2, 3):
+        audio_only(lanes=L)
