@@ -45,8 +45,8 @@ HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measur
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--windows", type=int, default=710, help="windows per GPU per step (configs[1] = 710)")
     ap.add_argument("--windows-per-recording", type=int, default=15, help="cmp:39 MAX_WINDOWS")
     ap.add_argument("--band", default="beta")
