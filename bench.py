@@ -52,6 +52,7 @@ def main():
     ap.add_argument("--band", default="beta")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="launch every step eagerly instead of replaying a HIP graph")
     ap.add_argument("--lanes", type=int, default=int(os.environ.get("TDA_LANES", "3")),
                     help="batches in flight (pipeline.Lanes): 1 = strictly one step after the other")
     ap.add_argument("--share-gpu", action="store_true",
@@ -86,39 +87,61 @@ def main():
     aud = synth.audio_windows(n_win, args.band, seed=4242 + 100000 * rank)
     eeg_t = torch.from_numpy(eeg).to(device)
     aud_t = torch.from_numpy(aud).to(device)
-    lanes = pipeline.Lanes(args.lanes, n_win, seg_off, device)
+    lanes = pipeline.Lanes(args.lanes, n_win, seg_off, device, graph=not args.no_graph)
     shards = [np.arange(r * n_seg, (r + 1) * n_seg) for r in range(world)]
     gather = (lambda res: tdist.all_gather_rows(res, shards[rank], shards, world * n_seg)) if world > 1 else None
 
-    def step(timers=None):
-        return lanes.submit(eeg_t, aud_t, ctx=ctx, timers=timers, post=gather)
+    # dominant kernel: rips_cloud_kernel (first pass of stage rips_audio).  The one-shot probe of the C ABI is armed
+    # before every launch (and before the capture of a lane's graph, so that it is baked into the replays): the kernel
+    # accumulates its own duration (first workgroup start .. last workgroup end, 100 MHz wall clock) in a per-lane
+    # device buffer; in the eager warm-up steps HIP events bracket the same launch on its stream.
+    DOM = "rips_audio"
+    span_init = np.zeros((lanes.depth, 4), np.int64)
+    spans = torch.from_numpy(span_init).to(device)
+    cur_events = [None]
 
-    for _ in range(max(args.warmup, lanes.depth)):
+    def arm(i):
+        ev = cur_events[0]
+        ctx.arm_probe(DOM, ev[0] if ev else None, ev[1] if ev else None, spans[i].data_ptr())
+    lanes.before_step = arm
+
+    def step(timers=None):
+        # the inputs were uploaded before the loop and never change: no wait on the caller's stream
+        return lanes.submit(eeg_t, aud_t, ctx=ctx, timers=timers, post=gather, sync_inputs=False)
+
+    # ---- warm-up: eager steps with per-stage events (stage_ms, event_ms), then one more round of the lanes, which in
+    # graph mode captures each lane's step ----
+    n_eager = max(args.warmup, lanes.depth)
+    ev_log, probes = [], []
+    for _ in range(n_eager):
+        timers = {s: (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                  for s in pipeline.STAGES}
+        cur_events[0] = (ctx.new_event(), ctx.new_event())
+        probes.append(cur_events[0])
+        out = step(timers)
+        ev_log.append(timers)
+    cur_events[0] = None
+    for _ in range(lanes.depth):
         out = step()
     torch.cuda.synchronize()
     for ws in lanes.ws:
         if not bool(((ws.eeg.status == 0) & ((ws.aud.status & ~4) == 0) & (ws.ws0 == 0) & (ws.ws1 == 0)).all()):
             raise SystemExit("bench: a window reported a non-zero status (overflow / not converged)")
-
     stage_ms = {s: 0.0 for s in pipeline.STAGES}
-    # dominant kernel: rips_cloud_kernel (first pass of stage rips_audio).  A one-shot probe of the C ABI
-    # brackets exactly that kernel with HIP events on its launch stream, every timed step.
-    DOM = "rips_audio"
-    probes = [(ctx.new_event(), ctx.new_event()) for _ in range(args.steps)]
-    # device-side span of the same kernel (first workgroup start .. last workgroup end, 100 MHz wall clock)
-    span_init = np.tile(np.array([np.iinfo(np.int64).max, 0], np.int64), (args.steps, 1))
-    spans = torch.from_numpy(span_init).to(device)
+    for evs in ev_log:
+        for s, (a, b) in evs.items():
+            stage_ms[s] += a.elapsed_time(b)
+    stage_ms = {s: v / n_eager for s, v in stage_ms.items()}
+    event_ms = sum(ctx.elapsed_ms(a, b) for a, b in probes) / n_eager
+    spans.copy_(torch.from_numpy(span_init))          # the timed region starts from empty accumulators
+
+    # ---- timed region ----
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    ev_log = []
     for k in range(args.steps):
-        timers = {s: (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-                  for s in pipeline.STAGES}
-        ctx.arm_probe(DOM, probes[k][0], probes[k][1], spans[k].data_ptr())
-        out = step(timers)          # events are recorded on the launch stream, read after the loop
-        ev_log.append(timers)
+        out = step()
     t_enq = time.perf_counter() - t0        # host time to enqueue all steps (GPU-bound if << dt)
     torch.cuda.synchronize()
     if world > 1:
@@ -128,18 +151,15 @@ def main():
         t = torch.tensor([dt], dtype=torch.float64, device="cpu" if args.share_gpu else device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    for evs in ev_log:
-        for s, (a, b) in evs.items():
-            stage_ms[s] += a.elapsed_time(b)
-    stage_ms = {s: v / args.steps for s, v in stage_ms.items()}
 
     if rank == 0:
         total_windows = world * n_win * args.steps
         value = total_windows / dt
         dom = DOM
-        event_ms = sum(ctx.elapsed_ms(a, b) for a, b in probes) / args.steps
         sp = spans.cpu().numpy()
-        kernel_ms = float(np.mean(sp[:, 1] - sp[:, 0])) / 100e6 * 1e3        # what a kernel trace reports
+        launches = int(sp[:, 3].sum())
+        assert launches == args.steps, f"probe saw {launches} launches of the dominant kernel, expected {args.steps}"
+        kernel_ms = float(sp[:, 2].sum()) / launches / 100e6 * 1e3           # what a kernel trace reports
         achieved = ALG_BYTES[dom] * n_win / (kernel_ms * 1e-3) / 1e9
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
@@ -158,8 +178,8 @@ def main():
                                    f"Takens dim 3 sub 2), Wasserstein H0+H1, H1 features, per-recording "
                                    f"({wpr} windows) reductions" + ("; one all-gather of result rows" if world > 1 else ""),
                        "windows_per_gpu": n_win, "thresh": 2.0, "parallelism": f"recordings sharded x{world}",
-                       "batches_in_flight": lanes.depth},
-            "stage_ms": {s: round(v, 4) for s, v in stage_ms.items()},
+                       "batches_in_flight": lanes.depth, "hip_graph": lanes.graph},
+            "stage_ms": {s: round(v, 4) for s, v in stage_ms.items()},       # eager warm-up steps, overlapping lanes
             "host_enqueue_ms_per_step": round(t_enq / args.steps * 1e3, 4),
             "roofline": {"bound": "hbm", "kernel": "rips_cloud_kernel<512, 1, unsigned int> (stage rips_audio)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -167,11 +187,11 @@ def main():
                          "event_ms": round(event_ms, 4),
                          "alg_bytes_per_launch": ALG_BYTES[dom] * n_win,
                          "note": "irregular integer work in LDS/registers (LDS latency/issue bound); the HBM fraction is "
-                                 "small by construction.  Averages over the timed steps.  event_ms: HIP events around "
-                                 "that one kernel on its launch stream -- with several batches in flight it includes the "
-                                 "time the grid waits for CU slots held by the other batches.  kernel_ms: first workgroup "
-                                 "start to last workgroup end, stamped by the kernel itself (100 MHz wall clock) -- the "
-                                 "interval rocprofv3 --kernel-trace reports; `achieved` uses it"},
+                                 "small by construction.  kernel_ms: average over every launch of the timed region of "
+                                 "(first workgroup start .. last workgroup end), stamped by the kernel itself (100 MHz wall "
+                                 "clock) -- the interval rocprofv3 --kernel-trace reports; `achieved` uses it.  event_ms: HIP "
+                                 "events around the same launch on its stream in the eager warm-up steps; with several "
+                                 "batches in flight it includes the time the grid waits for CU slots held by the others"},
         }
         if not args.no_cpu:
             line["cpu_baseline"] = cpu_baseline(eeg, aud, seg_off, args.cpu_seconds)

@@ -259,10 +259,12 @@ tda_status tda_stream_sync(tda_ctx* ctx, void* stream);
  * context records ev_start right before and ev_stop right after that ONE kernel on its stream
  * (the retry passes and the row-ordering kernel of the same call are outside the bracket).  This is
  * the per-kernel duration bench.py's roofline uses; rocprofv3 --kernel-trace reports the same kernel.
- * dev_span (optional, TDA_PROBE_RIPS_CLOUD only): device u64[2] preset to {~0, 0}; the kernel leaves
- * the 100 MHz wall-clock time of its first workgroup start and last workgroup end there -- the
- * interval a kernel trace shows, i.e. without the time the grid waits for CU slots behind other
- * in-flight batches. */
+ * dev_span (optional, TDA_PROBE_RIPS_CLOUD only): device u64[4] preset to 0.  Workgroup 0 (dispatched
+ * first) stores the 100 MHz wall-clock time of its start in [0]; finished workgroups are counted in [1];
+ * the last one adds (its end - that start) -- the interval a kernel trace shows, i.e. without the time
+ * the grid waits for CU slots behind other in-flight batches -- to [2], counts the launch in [3] and
+ * resets [1].  A launch captured into a HIP graph with the probe armed therefore measures every replay;
+ * average duration = [2] / [3] / 100 MHz.  The events may be NULL when dev_span is given. */
 #define TDA_PROBE_NONE       0
 #define TDA_PROBE_RIPS_CLOUD 1   /* rips_cloud_kernel, first pass (tda_takens_rips_batch / tda_cloud_rips_batch) */
 #define TDA_PROBE_RIPS_DM    2   /* rips_dm_kernel, first pass (tda_rips_dm_batch) */

@@ -138,8 +138,9 @@ class Context:
         self.check(self.lib.tda_event_create(self.h, C.byref(ev)))
         return ev
 
-    def arm_probe(self, stage, ev_start, ev_stop, dev_span=None):
-        """dev_span: optional device pointer (int) to u64[2] = {~0, 0} (rips_audio only)."""
+    def arm_probe(self, stage, ev_start=None, ev_stop=None, dev_span=None):
+        """dev_span: optional device pointer (int) to a zeroed u64[4] (rips_audio only): the kernel
+        accumulates its own duration there (see include/tdaeeg.h); events may be omitted then."""
         self.check(self.lib.tda_set_kernel_probe(self.h, self.PROBES[stage], ev_start, ev_stop,
                                                  c_vp(dev_span) if dev_span else None))
 

@@ -593,7 +593,9 @@ tda_status tda_set_kernel_probe(tda_ctx* ctx, int which, void* ev_start, void* e
 {
     CHECK_CTX(ctx);
     if (which < TDA_PROBE_NONE || which > TDA_PROBE_CORR_DIST) TDA_FAIL(ctx, TDA_ERR_INVALID, "unknown probe");
-    if (which != TDA_PROBE_NONE && (!ev_start || !ev_stop)) TDA_FAIL(ctx, TDA_ERR_INVALID, "probe needs two events");
+    if (which != TDA_PROBE_NONE && !(ev_start && ev_stop) && !dev_span)
+        TDA_FAIL(ctx, TDA_ERR_INVALID, "probe needs two events or a span buffer");
+    if ((ev_start == nullptr) != (ev_stop == nullptr)) TDA_FAIL(ctx, TDA_ERR_INVALID, "probe events come in pairs");
     ctx->probe_which = which;
     ctx->probe_start = (hipEvent_t)ev_start;
     ctx->probe_stop = (hipEvent_t)ev_stop;

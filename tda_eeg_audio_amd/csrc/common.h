@@ -20,21 +20,22 @@ struct tda_ctx {
     // one-shot kernel probe (tda_set_kernel_probe)
     int probe_which = 0;
     hipEvent_t probe_start = nullptr, probe_stop = nullptr;
-    unsigned long long* probe_span = nullptr;   // device u64[2] {~0, 0}: first workgroup start / last workgroup end
+    unsigned long long* probe_span = nullptr;   // device u64[4] {~0, 0, 0, 0}: see rips_cloud_kernel
 };
 
 // brackets ONE kernel launch with the armed probe events (if `which` is armed)
 struct ProbeScope {
     tda_ctx* ctx; hipStream_t st; bool on; unsigned long long* span;
     ProbeScope(tda_ctx* c, int which, hipStream_t s)
-        : ctx(c), st(s), on(c->probe_which == which && c->probe_start && c->probe_stop), span(c->probe_span)
+        : ctx(c), st(s), on(c->probe_which == which && ((c->probe_start && c->probe_stop) || c->probe_span)),
+          span(c->probe_span)
     {
-        if (on) (void)hipEventRecord(ctx->probe_start, st);
+        if (on && ctx->probe_start) (void)hipEventRecord(ctx->probe_start, st);
     }
     ~ProbeScope()
     {
         if (on) {
-            (void)hipEventRecord(ctx->probe_stop, st);
+            if (ctx->probe_stop) (void)hipEventRecord(ctx->probe_stop, st);
             ctx->probe_which = 0; ctx->probe_start = ctx->probe_stop = nullptr; ctx->probe_span = nullptr;
         }
     }

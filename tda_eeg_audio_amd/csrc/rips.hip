@@ -1183,16 +1183,27 @@ rips_cloud_kernel(const double* __restrict__ src, const int* __restrict__ tau_or
                   unsigned long long* __restrict__ span)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    // armed probe only: span[0] = earliest workgroup start, span[1] = latest workgroup end (100 MHz wall clock),
-    // i.e. the interval a kernel trace reports for this launch
-    if (span && threadIdx.x == 0) atomicMin(&span[0], wall_clock64());
+    // armed probe only (100 MHz wall clock): span[0] = start of workgroup 0 of this launch, span[1] = workgroups
+    // done; the last workgroup adds (its end - that start), the interval a kernel trace reports, to span[2], counts
+    // the launch in span[3] and re-arms the counter, so that a launch baked into a HIP graph keeps measuring.  (One
+    // store at the start: 512 simultaneous atomics on one address cost ~50 us per launch.)
+    if (span && blockIdx.x == 0 && threadIdx.x == 0)      // workgroups are dispatched in order: 0 starts first
+        atomicExch(&span[0], wall_clock64());
     for (int win = blockIdx.x; win < n_win; win += gridDim.x) {
         if (retry_only && !(out.status[win] & TDA_WIN_CLASS_OVERFLOW)) continue;   // workgroup-uniform
         rips_cloud_window<NT, W, WT>(smem, win, src, tau_or_npts, n_t_or_pcap, dim, subsample, mode, normalise,
                                      thresh, L, p_max, n_points, out);
         __syncthreads();
     }
-    if (span && threadIdx.x == 0) atomicMax(&span[1], wall_clock64());
+    if (span && threadIdx.x == 0) {                        // device-scope atomics only: a fence would write L2 back
+        const unsigned long long now = wall_clock64();
+        if (atomicAdd(&span[1], 1ull) == (unsigned long long)gridDim.x - 1ull) {
+            const unsigned long long first = atomicAdd(&span[0], 0ull);
+            atomicAdd(&span[2], now - first);
+            atomicAdd(&span[3], 1ull);
+            atomicExch(&span[1], 0ull);
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------

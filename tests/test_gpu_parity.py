@@ -439,3 +439,12 @@ def test_pipeline_step_vs_oracle_and_lanes(ctx):
     torch.cuda.synchronize()
     for k in range(5):
         assert np.array_equal(got[k].cpu().numpy(), serial[k], equal_nan=True), k
+    # the same through captured HIP graphs (one per lane and input buffer pair), replayed twice
+    glanes = pipeline.Lanes(2, n_win, seg_off, dev, graph=True)
+    for rnd in range(2):
+        got = [glanes.submit(eeg_t, aud_t, ctx=ctx, post=lambda r: r.clone()) for _, _, eeg_t, aud_t in batches[:4]]
+        glanes.drain()
+        torch.cuda.synchronize()
+        for k in range(4):
+            assert np.array_equal(got[k].cpu().numpy(), serial[k], equal_nan=True), (rnd, k)
+    assert len(glanes.graphs) == 4
