@@ -10,7 +10,7 @@ TAG=${1:-r01}
 OUT=gpurun_out
 mkdir -p $OUT
 export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_stats -o stats -- python3 bench.py --no-cpu --steps 20 --warmup 3 > $OUT/${TAG}_bench_under_rocprof.json 2> $OUT/prof_stats.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_stats -o stats -- python3 bench.py --no-cpu --steps 40 --warmup 4 > $OUT/${TAG}_bench_under_rocprof.json 2> $OUT/prof_stats.err
 echo "stats pass done"
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/prof_fetch -o fetch -- python3 bench.py --no-cpu --steps 4 --warmup 1 --lanes 1 > /dev/null 2> $OUT/prof_fetch.err
 echo "FETCH_SIZE pass done"
