@@ -189,6 +189,12 @@ tda_status tda_hilbert_envelope(tda_ctx* ctx, const double* x, int n, const doub
 tda_status tda_tau_batch_dev(tda_ctx* ctx, const double* win, int n_win, int n_t, int max_lag,
                              int* tau, void* stream);
 tda_status tda_tau_batch(tda_ctx* ctx, const double* win, int n_win, int n_t, int max_lag, int* tau);
+/* The driver's use of it (scripts/tda_eeg_audio_comparison.py:83, scripts/matched_vs_mismatched.py:56): one tau per
+ * (recording, band) group, from the FIRST window of the group (window seg_off[g] of win).  tau_seg: (n_seg);
+ * tau_win (nullable): (n_total) receives the group's value for each of its windows, the per-window array
+ * tda_takens_rips_batch takes.  Device pointers only (a stage of the batched driver). */
+tda_status tda_tau_segments_dev(tda_ctx* ctx, const double* win, const int* seg_off, int n_seg, int n_t,
+                                int max_lag, int* tau_seg, int* tau_win, void* stream);
 
 /* ---- 11 scalar features per diagram ------------------------------------------
  * replaces extract_features (scripts/utils.py:144-177) ==
@@ -219,6 +225,14 @@ tda_status tda_segment_nanmean_dev(tda_ctx* ctx, const double* x, const int* seg
                                    double* out, void* stream);
 tda_status tda_segment_nanmean(tda_ctx* ctx, const double* x, const int* seg_off, int n_seg,
                                int n_total, double* out);
+
+/* ---- one result row per (recording, band) group ---------------------------------------
+ * out: (n_seg, 48) float64 = [ nanmean of w_h0 (cmp:117), nanmean of w_h1 (cmp:118), tau (cmp:83), number of
+ * windows, the 44 values of tda_aggregate_batch (v2:429-436) ] -- tda_segment_nanmean x 2 + tda_aggregate_batch
+ * + the row assembly in ONE launch; the rows are what the GPUs of a node exchange.  Device pointers only. */
+tda_status tda_recording_rows_dev(tda_ctx* ctx, const double* w_h0, const double* w_h1, const int* tau_seg,
+                                  const double* feat_h0, const double* feat_h1, const int* seg_off,
+                                  int n_seg, double* out, void* stream);
 
 /* ---- Spearman correlation of feature time series ------------------------------------
  * replaces the spearmanr(a_ts, e_ts) loop of process_recording

@@ -57,6 +57,8 @@ SYMBOLS = {
     "tda_hilbert_envelope_dev": (_I, [c_vp, c_vp, _I, c_vp, c_vp, c_vp]),
     "tda_hilbert_envelope": (_I, [c_vp, c_vp, _I, c_vp, c_vp]),
     "tda_tau_batch_dev": (_I, [c_vp, c_vp, _I, _I, _I, c_vp, c_vp]),
+    "tda_tau_segments_dev": (_I, [c_vp, c_vp, c_vp, _I, _I, _I, c_vp, c_vp, c_vp]),
+    "tda_recording_rows_dev": (_I, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, _I, c_vp, c_vp]),
     "tda_tau_batch": (_I, [c_vp, c_vp, _I, _I, _I, c_vp]),
     "tda_features_batch_dev": (_I, [c_vp, c_vp, c_vp, _I, _I, c_vp, c_vp]),
     "tda_features_batch": (_I, [c_vp, c_vp, c_vp, _I, _I, c_vp]),

@@ -165,6 +165,24 @@ tda_status tda_tau_batch_dev(tda_ctx* ctx, const double* win, int n_win, int n_t
     return launch_tau(ctx, win, n_win, n_t, max_lag, tau, (hipStream_t)stream);
 }
 
+tda_status tda_tau_segments_dev(tda_ctx* ctx, const double* win, const int* seg_off, int n_seg, int n_t, int max_lag,
+                                int* tau_seg, int* tau_win, void* stream)
+{
+    CHECK_CTX(ctx); CHECK_NONNEG(ctx, n_seg);
+    if (n_seg) { CHECK_PTR(ctx, win); CHECK_PTR(ctx, seg_off); CHECK_PTR(ctx, tau_seg); }
+    return launch_tau_segments(ctx, win, seg_off, n_seg, n_t, max_lag, tau_seg, tau_win, (hipStream_t)stream);
+}
+
+tda_status tda_recording_rows_dev(tda_ctx* ctx, const double* w_h0, const double* w_h1, const int* tau_seg,
+                                  const double* feat_h0, const double* feat_h1, const int* seg_off, int n_seg,
+                                  double* out, void* stream)
+{
+    CHECK_CTX(ctx); CHECK_NONNEG(ctx, n_seg);
+    if (n_seg) { CHECK_PTR(ctx, w_h0); CHECK_PTR(ctx, w_h1); CHECK_PTR(ctx, tau_seg); CHECK_PTR(ctx, feat_h0);
+                 CHECK_PTR(ctx, feat_h1); CHECK_PTR(ctx, seg_off); CHECK_PTR(ctx, out); }
+    return launch_recording_rows(ctx, w_h0, w_h1, tau_seg, feat_h0, feat_h1, seg_off, n_seg, out, (hipStream_t)stream);
+}
+
 tda_status tda_features_batch_dev(tda_ctx* ctx, const double* dgm, const int* cnt, int n_dgm, int cap, double* feat,
                                   void* stream)
 {

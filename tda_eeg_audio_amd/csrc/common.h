@@ -149,6 +149,9 @@ tda_status launch_upfirdn(tda_ctx*, const double*, long long, const double*, int
                           hipStream_t);
 tda_status launch_hilbert_env(tda_ctx*, const double*, int, const double*, double*, hipStream_t);
 tda_status launch_tau(tda_ctx*, const double*, int, int, int, int*, hipStream_t);
+tda_status launch_tau_segments(tda_ctx*, const double*, const int*, int, int, int, int*, int*, hipStream_t);
+tda_status launch_recording_rows(tda_ctx*, const double*, const double*, const int*, const double*, const double*, const int*,
+                                 int, double*, hipStream_t);
 tda_status launch_features(tda_ctx*, const double*, const int*, int, int, double*, hipStream_t);
 tda_status launch_aggregate(tda_ctx*, const double*, const double*, const int*, int, double*, hipStream_t);
 tda_status launch_nanmean(tda_ctx*, const double*, const int*, int, double*, hipStream_t);

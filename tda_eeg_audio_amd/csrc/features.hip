@@ -48,14 +48,23 @@ __device__ double np_pairwise_sum(const double* a, int n, int stride)
 // One wave per window; lane l owns lags l+1 and l+65 (max_lag <= 128), each a
 // sequential fma chain over t (the order oracle/tda_oracle.c::orc_compute_tau fixes).
 // ---------------------------------------------------------------------------------
+// seg_off != nullptr: workgroup g handles the FIRST window of group g (tda_eeg_audio_comparison.py:83: tau is
+// computed once per recording-band, from its first selected window) and also writes the value to every
+// window of the group in tau_win, the per-window array the Takens kernel takes.
 __global__ void __launch_bounds__(64)
-tau_kernel(const double* __restrict__ win, int n_win, int n_t, int max_lag, int* __restrict__ tau)
+tau_kernel(const double* __restrict__ win, int n_win, int n_t, int max_lag, int* __restrict__ tau,
+           const int* __restrict__ seg_off, int* __restrict__ tau_win)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     double* sc = reinterpret_cast<double*>(smem);
-    const int w = blockIdx.x;
-    if (w >= n_win) return;
+    const int g = blockIdx.x;
+    if (g >= n_win) return;                          // n_win = number of groups in segment mode
     const int lane = lane_id();
+    int w = g, w_end = g + 1;
+    if (seg_off) {
+        w = seg_off[g]; w_end = seg_off[g + 1];
+        if (w_end <= w) { if (lane == 0) tau[g] = 0; return; }      // empty group
+    }
     const double* s = win + (size_t)w * n_t;
     for (int t = lane; t < n_t; t += 64) sc[t] = s[t];
     __syncthreads();
@@ -80,7 +89,9 @@ tau_kernel(const double* __restrict__ win, int n_win, int n_t, int max_lag, int*
         if (bal) found = k0 + __builtin_ctzll(bal);
     }
     if (!found) { found = max_lag / 10; if (found < 1) found = 1; }
-    if (lane == 0) tau[w] = found;
+    if (lane == 0) tau[g] = found;
+    if (tau_win)
+        for (int i = w + lane; i < w_end; i += 64) tau_win[i] = found;
 }
 
 // ---------------------------------------------------------------------------------
@@ -212,6 +223,55 @@ nanmean_kernel(const double* __restrict__ x, const int* __restrict__ seg_off, in
     out[seg] = cnt > 0 ? sum / (double)cnt : __longlong_as_double(0x7ff8000000000000ll);
 }
 
+// ---------------------------------------------------------------------------------
+// One row per (recording, band) group, the unit the GPUs exchange:
+//   [ nanmean W_H0 (cmp:117), nanmean W_H1 (cmp:118), tau (cmp:83), n_windows, 44 aggregated EEG features (v2:429-436) ]
+// = nanmean_kernel x 2 + aggregate_kernel + the row assembly in one launch (lanes 0..21 aggregate, 22/23 nanmean).
+// ---------------------------------------------------------------------------------
+__global__ void __launch_bounds__(64)
+recording_rows_kernel(const double* __restrict__ w0, const double* __restrict__ w1, const int* __restrict__ tau_seg,
+                      const double* __restrict__ f0, const double* __restrict__ f1, const int* __restrict__ seg_off,
+                      int n_seg, double* __restrict__ out)
+{
+    const int seg = blockIdx.x;
+    if (seg >= n_seg) return;
+    const int lane = lane_id();
+    const int s0 = seg_off[seg], s1 = seg_off[seg + 1];
+    const int n = s1 - s0;
+    double* row = out + (size_t)seg * (4 + 4 * TDA_N_FEATURES);
+    if (lane < 2 * TDA_N_FEATURES) {
+        const int h = lane / TDA_N_FEATURES, f = lane % TDA_N_FEATURES;
+        const double* src = (h == 0 ? f0 : f1) + (size_t)s0 * TDA_N_FEATURES + f;
+        double mean = 0.0, sd = 0.0;
+        if (n > 0) {
+            mean = np_pairwise_sum(src, n, TDA_N_FEATURES) / (double)n;
+            auto sq = [=](int i) { const double z = src[(size_t)i * TDA_N_FEATURES] - mean; return z * z; };
+            sd = sqrt(np_pairwise_fn(sq, 0, n) / (double)n);
+        }
+        row[4 + f * 4 + h * 2] = mean;
+        row[4 + f * 4 + h * 2 + 1] = sd;
+    } else if (lane < 2 * TDA_N_FEATURES + 2) {
+        const double* x = lane == 2 * TDA_N_FEATURES ? w0 : w1;
+        int cnt = 0;
+        for (int i = s0; i < s1; ++i) cnt += (x[i] == x[i]) ? 1 : 0;
+        auto val = [=](int i) { const double v = x[s0 + i]; return v == v ? v : 0.0; };
+        const double sum = np_pairwise_fn(val, 0, n);
+        row[lane - 2 * TDA_N_FEATURES] = cnt > 0 ? sum / (double)cnt : __longlong_as_double(0x7ff8000000000000ll);
+    } else if (lane == 2 * TDA_N_FEATURES + 2) {
+        row[2] = (double)tau_seg[seg];
+        row[3] = (double)n;
+    }
+}
+
+tda_status launch_recording_rows(tda_ctx* ctx, const double* w0, const double* w1, const int* tau_seg, const double* f0,
+                                 const double* f1, const int* seg_off, int n_seg, double* out, hipStream_t st)
+{
+    if (n_seg == 0) return TDA_OK;
+    hipLaunchKernelGGL(recording_rows_kernel, dim3(n_seg), dim3(64), 0, st, w0, w1, tau_seg, f0, f1, seg_off, n_seg, out);
+    TDA_HIP(ctx, hipGetLastError());
+    return TDA_OK;
+}
+
 tda_status launch_nanmean(tda_ctx* ctx, const double* x, const int* seg_off, int n_seg, double* out, hipStream_t st)
 {
     if (n_seg == 0) return TDA_OK;
@@ -284,7 +344,19 @@ tda_status launch_tau(tda_ctx* ctx, const double* win, int n_win, int n_t, int m
 {
     if (n_win == 0) return TDA_OK;
     if (n_t < 2 || n_t > 8192) TDA_FAIL(ctx, TDA_ERR_UNSUPPORTED, "n_t must be in [2,8192]");
-    hipLaunchKernelGGL(tau_kernel, dim3(n_win), dim3(64), (size_t)n_t * 8, st, win, n_win, n_t, max_lag, tau);
+    hipLaunchKernelGGL(tau_kernel, dim3(n_win), dim3(64), (size_t)n_t * 8, st, win, n_win, n_t, max_lag, tau,
+                       (const int*)nullptr, (int*)nullptr);
+    TDA_HIP(ctx, hipGetLastError());
+    return TDA_OK;
+}
+
+tda_status launch_tau_segments(tda_ctx* ctx, const double* win, const int* seg_off, int n_seg, int n_t, int max_lag,
+                               int* tau_seg, int* tau_win, hipStream_t st)
+{
+    if (n_seg == 0) return TDA_OK;
+    if (n_t < 2 || n_t > 8192) TDA_FAIL(ctx, TDA_ERR_UNSUPPORTED, "n_t must be in [2,8192]");
+    hipLaunchKernelGGL(tau_kernel, dim3(n_seg), dim3(64), (size_t)n_t * 8, st, win, n_seg, n_t, max_lag, tau_seg, seg_off,
+                       tau_win);
     TDA_HIP(ctx, hipGetLastError());
     return TDA_OK;
 }

@@ -303,6 +303,34 @@ def tau_dev(win_t, max_lag=None, tau_t=None, ctx=None):
     return tau_t
 
 
+def tau_segments_dev(win_t, seg_off_t, max_lag=None, tau_seg_t=None, tau_win_t=None, ctx=None):
+    """cmp:83 / mvm:56: tau of every (recording, band) group from its first window; tau_win_t (optional, (n_win,)
+    int32) receives the group's value for every window."""
+    import torch
+    ctx = ctx or get_ctx()
+    n_win, n_t = win_t.shape
+    n_seg = seg_off_t.numel() - 1
+    if tau_seg_t is None:
+        tau_seg_t = torch.empty(n_seg, dtype=torch.int32, device=win_t.device)
+    ctx.check(ctx.lib.tda_tau_segments_dev(ctx.h, _tp(win_t), _tp(seg_off_t), n_seg, n_t,
+                                           -1 if max_lag is None else int(max_lag), _tp(tau_seg_t), _tp(tau_win_t),
+                                           _stream()))
+    return tau_seg_t
+
+
+def recording_rows_dev(w0_t, w1_t, tau_seg_t, fe0_t, fe1_t, seg_off_t, out_t=None, ctx=None):
+    """(n_seg, 48) rows [nanmean W_H0, nanmean W_H1, tau, n_windows, 44 aggregated features] in one launch."""
+    import torch
+    ctx = ctx or get_ctx()
+    n_seg = seg_off_t.numel() - 1
+    if out_t is None:
+        out_t = torch.empty((n_seg, 4 + 4 * _lib.N_FEATURES), dtype=torch.float64, device=w0_t.device)
+    assert out_t.is_contiguous()
+    ctx.check(ctx.lib.tda_recording_rows_dev(ctx.h, _tp(w0_t), _tp(w1_t), _tp(tau_seg_t), _tp(fe0_t), _tp(fe1_t),
+                                             _tp(seg_off_t), n_seg, _tp(out_t), _stream()))
+    return out_t
+
+
 def features_dev(rows_t, cnt_t, feat_t=None, ctx=None):
     import torch
     ctx = ctx or get_ctx()

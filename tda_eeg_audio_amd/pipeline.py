@@ -36,6 +36,7 @@ class Workspace:
         self.eeg = engine.DeviceDiagrams(n_win, n_ch, h1_cap, device)
         self.aud = engine.DeviceDiagrams(n_win, 128, h1_cap, device)
         self.tau_seg = torch.empty(self.n_seg, dtype=torch.int32, device=device)
+        self.tau_win = torch.empty(n_win, dtype=torch.int32, device=device)
         self.w0 = torch.empty(n_win, **f64); self.w1 = torch.empty(n_win, **f64)
         self.ws0 = torch.empty(n_win, dtype=torch.int32, device=device)
         self.ws1 = torch.empty(n_win, dtype=torch.int32, device=device)
@@ -64,8 +65,8 @@ def run_step(eeg_win, audio_win, ws, ctx=None, max_lag=125, timers=None):
         return r
 
     # The EEG chain (corr->dist->Rips) and the audio chain (tau->Takens->Rips) are independent until
-    # the Wasserstein step: the EEG kernels (31 KB LDS per workgroup) run on a side stream and
-    # co-reside on the CUs with the audio kernel (113 KB), filling its idle issue slots.
+    # the Wasserstein step: the EEG kernels run on a side stream and share the GPU with the audio kernel
+    # (two 78 KB workgroups per CU at most), which leaves CUs idle in the tail of its grid.
     main = torch.cuda.current_stream()
     side = ws.side_stream if ws.overlap else main
     if ws.overlap:
@@ -78,13 +79,10 @@ def run_step(eeg_win, audio_win, ws, ctx=None, max_lag=125, timers=None):
         def eeg_feats():
             engine.features_dev(ws.eeg.h0, ws.eeg.c0, ws.fe0, ctx=ctx)
             engine.features_dev(ws.eeg.h1, ws.eeg.c1, ws.fe1, ctx=ctx)
-            ws.result[:, 4:] = engine.aggregate_dev(ws.fe0, ws.fe1, ws.seg_off, ctx=ctx)
         stage("features_eeg", eeg_feats)
-    # tau from the first selected window of each recording-band (cmp:83), broadcast to its windows
-    first = audio_win.index_select(0, ws.first_idx)
-    stage("tau", lambda: engine.tau_dev(first, max_lag, ws.tau_seg, ctx=ctx))
-    tau_w = ws.tau_seg.index_select(0, ws.rec_id)
-    stage("rips_audio", lambda: engine.takens_rips_dev(audio_win, tau_w, ws.aud, ctx=ctx))
+    # tau from the first selected window of each recording-band (cmp:83), written per group and per window
+    stage("tau", lambda: engine.tau_segments_dev(audio_win, ws.seg_off, max_lag, ws.tau_seg, ws.tau_win, ctx=ctx))
+    stage("rips_audio", lambda: engine.takens_rips_dev(audio_win, ws.tau_win, ws.aud, ctx=ctx))
     stage("features_audio", lambda: engine.features_dev(ws.aud.h1, ws.aud.c1, ws.fa1, ctx=ctx))
     if ws.overlap:
         main.wait_stream(side)
@@ -92,14 +90,10 @@ def run_step(eeg_win, audio_win, ws, ctx=None, max_lag=125, timers=None):
                                                            out_t=ws.w0, status_t=ws.ws0, ctx=ctx))
     stage("wasserstein_h1", lambda: engine.wasserstein_dev(ws.eeg.h1, ws.eeg.c1, ws.aud.h1, ws.aud.c1,
                                                            out_t=ws.w1, status_t=ws.ws1, ctx=ctx))
-
-    # per recording-band reductions (cmp:117-118)
-    def agg():
-        ws.result[:, 0] = engine.segment_nanmean_dev(ws.w0, ws.seg_off, ctx=ctx)
-        ws.result[:, 1] = engine.segment_nanmean_dev(ws.w1, ws.seg_off, ctx=ctx)
-        ws.result[:, 2] = ws.tau_seg.to(torch.float64)
-        ws.result[:, 3] = ws.n_win_seg
-    stage("reduce", agg)
+    # per recording-band rows: nanmean of the distances (cmp:117-118), tau, window count, mean/std of the EEG
+    # features (v2:429-436) -- one launch
+    stage("reduce", lambda: engine.recording_rows_dev(ws.w0, ws.w1, ws.tau_seg, ws.fe0, ws.fe1, ws.seg_off, ws.result,
+                                                      ctx=ctx))
     return ws.result
 
 

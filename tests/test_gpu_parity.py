@@ -448,3 +448,31 @@ def test_pipeline_step_vs_oracle_and_lanes(ctx):
         for k in range(4):
             assert np.array_equal(got[k].cpu().numpy(), serial[k], equal_nan=True), (rnd, k)
     assert len(glanes.graphs) == 4
+
+
+def test_fused_row_kernels_equal_their_parts(ctx):
+    """tda_tau_segments_dev == tda_tau_batch_dev on the first window of each group (broadcast per window);
+    tda_recording_rows_dev == tda_segment_nanmean x 2 + tda_aggregate_batch + tau / count columns, bit for bit."""
+    import torch
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(5)
+    seg = np.array([0, 15, 16, 40, 40, 53], np.int32)              # includes a single-window and an empty group
+    n = int(seg[-1])
+    aud = torch.from_numpy(synth.audio_windows(n, "theta", seed=9)).to(dev)
+    seg_t = torch.from_numpy(seg).to(dev)
+    tau_w = torch.full((n,), -7, dtype=torch.int32, device=dev)
+    tau_s = engine.tau_segments_dev(aud, seg_t, 125, None, tau_w, ctx=ctx).cpu().numpy()
+    first = [int(s) for s, e in zip(seg[:-1], seg[1:]) if e > s]
+    ref = engine.tau_dev(aud[first].contiguous(), 125, ctx=ctx).cpu().numpy()
+    nonempty = np.diff(seg) > 0
+    assert np.array_equal(tau_s[nonempty], ref) and np.all(tau_s[~nonempty] == 0)
+    assert np.array_equal(tau_w.cpu().numpy(), np.repeat(tau_s, np.diff(seg)))
+    w0 = rng.random(n); w1 = rng.random(n); w1[3] = np.nan; w1[15] = np.nan        # group 1 is all-NaN in w1
+    f0 = rng.random((n, 11)); f1 = rng.random((n, 11))
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    rows = engine.recording_rows_dev(t(w0), t(w1), torch.from_numpy(tau_s).to(dev), t(f0), t(f1), seg_t, ctx=ctx).cpu().numpy()
+    assert np.array_equal(rows[:, 0], engine.segment_nanmean_dev(t(w0), seg_t, ctx=ctx).cpu().numpy(), equal_nan=True)
+    assert np.array_equal(rows[:, 1], engine.segment_nanmean_dev(t(w1), seg_t, ctx=ctx).cpu().numpy(), equal_nan=True)
+    assert np.isnan(rows[1, 1]) and np.isnan(rows[3, 0])
+    assert np.array_equal(rows[:, 2], tau_s.astype(np.float64)) and np.array_equal(rows[:, 3], np.diff(seg).astype(np.float64))
+    assert np.array_equal(rows[:, 4:], engine.aggregate_dev(t(f0), t(f1), seg_t, ctx=ctx).cpu().numpy())
