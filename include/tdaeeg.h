@@ -68,6 +68,17 @@ size_t     tda_last_error(const tda_ctx* ctx, char* buf, size_t cap);
 /* Capacity for simultaneously alive H1 classes = 64 * words, words in {1,2,4}.
  * Defaults: 2 for distance-matrix input, 1 for point clouds. */
 tda_status tda_set_class_words(tda_ctx* ctx, int words_dm, int words_cloud);
+/* How the Rips entry points treat windows that run out of class bits (TDA_WIN_CLASS_OVERFLOW).
+ * AUTO (default): every call launches its widening passes after the first pass; they redo only the flagged
+ *   windows, but each is a launch that needs (large) CU resources even when nothing is flagged.
+ * FIRST_PASS: only the first pass is launched; flagged windows keep the status bit and invalid rows.  A
+ *   streaming caller checks the statuses once they have reached the host and, if any is set, calls the same
+ *   entry point again on the same buffers under RETRY_ONLY (then recomputes what depends on the diagrams).
+ * RETRY_ONLY: only the widening passes (and the row ordering) are launched. */
+#define TDA_RETRY_AUTO       0
+#define TDA_RETRY_FIRST_PASS 1
+#define TDA_RETRY_ONLY       2
+tda_status tda_set_retry_policy(tda_ctx* ctx, int policy);
 
 /* ---- corr -> distance ------------------------------------------------------
  * replaces compute_correlation_matrix + correlation_to_distance(method="euclidean")
@@ -229,10 +240,14 @@ tda_status tda_segment_nanmean(tda_ctx* ctx, const double* x, const int* seg_off
 /* ---- one result row per (recording, band) group ---------------------------------------
  * out: (n_seg, 48) float64 = [ nanmean of w_h0 (cmp:117), nanmean of w_h1 (cmp:118), tau (cmp:83), number of
  * windows, the 44 values of tda_aggregate_batch (v2:429-436) ] -- tda_segment_nanmean x 2 + tda_aggregate_batch
- * + the row assembly in ONE launch; the rows are what the GPUs of a node exchange.  Device pointers only. */
+ * + the row assembly in ONE launch; the rows are what the GPUs of a node exchange.  Device pointers only.
+ * status_a / status_b / seg_flags (all nullable): per-window status arrays of the two Rips calls and an
+ * (n_seg) int32 output that receives, per group, the OR of their TDA_WIN_CLASS_OVERFLOW bits -- what a
+ * caller running under TDA_RETRY_FIRST_PASS copies to the host to decide about a retry. */
 tda_status tda_recording_rows_dev(tda_ctx* ctx, const double* w_h0, const double* w_h1, const int* tau_seg,
                                   const double* feat_h0, const double* feat_h1, const int* seg_off,
-                                  int n_seg, double* out, void* stream);
+                                  int n_seg, double* out, const int* status_a, const int* status_b,
+                                  int* seg_flags, void* stream);
 
 /* ---- Spearman correlation of feature time series ------------------------------------
  * replaces the spearmanr(a_ts, e_ts) loop of process_recording

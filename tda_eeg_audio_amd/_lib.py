@@ -58,7 +58,8 @@ SYMBOLS = {
     "tda_hilbert_envelope": (_I, [c_vp, c_vp, _I, c_vp, c_vp]),
     "tda_tau_batch_dev": (_I, [c_vp, c_vp, _I, _I, _I, c_vp, c_vp]),
     "tda_tau_segments_dev": (_I, [c_vp, c_vp, c_vp, _I, _I, _I, c_vp, c_vp, c_vp]),
-    "tda_recording_rows_dev": (_I, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, _I, c_vp, c_vp]),
+    "tda_recording_rows_dev": (_I, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, _I, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "tda_set_retry_policy": (_I, [c_vp, _I]),
     "tda_tau_batch": (_I, [c_vp, c_vp, _I, _I, _I, c_vp]),
     "tda_features_batch_dev": (_I, [c_vp, c_vp, c_vp, _I, _I, c_vp, c_vp]),
     "tda_features_batch": (_I, [c_vp, c_vp, c_vp, _I, _I, c_vp]),
@@ -131,6 +132,11 @@ class Context:
 
     def set_class_words(self, words_dm=2, words_cloud=1):
         self.check(self.lib.tda_set_class_words(self.h, words_dm, words_cloud))
+
+    RETRY_AUTO, RETRY_FIRST_PASS, RETRY_ONLY = 0, 1, 2
+
+    def set_retry_policy(self, policy):
+        self.check(self.lib.tda_set_retry_policy(self.h, int(policy)))
 
     # ---- one-shot kernel probe (bench.py roofline): HIP events around ONE first-pass kernel ----
     PROBES = {"rips_audio": 1, "rips_eeg": 2, "corr_dist": 3}

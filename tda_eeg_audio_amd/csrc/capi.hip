@@ -59,6 +59,14 @@ tda_status tda_set_class_words(tda_ctx* ctx, int words_dm, int words_cloud)
     return TDA_OK;
 }
 
+tda_status tda_set_retry_policy(tda_ctx* ctx, int policy)
+{
+    if (!ctx) return TDA_ERR_INVALID;
+    if (policy < TDA_RETRY_AUTO || policy > TDA_RETRY_ONLY) TDA_FAIL(ctx, TDA_ERR_INVALID, "unknown retry policy");
+    ctx->retry_policy = policy;
+    return TDA_OK;
+}
+
 #define CHECK_CTX(ctx) do { if (!(ctx)) return TDA_ERR_INVALID; } while (0)
 #define CHECK_PTR(ctx, p) do { if (!(p)) TDA_FAIL(ctx, TDA_ERR_INVALID, "null pointer: " #p); } while (0)
 #define CHECK_NONNEG(ctx, v) do { if ((v) < 0) TDA_FAIL(ctx, TDA_ERR_INVALID, "negative size: " #v); } while (0)
@@ -175,12 +183,13 @@ tda_status tda_tau_segments_dev(tda_ctx* ctx, const double* win, const int* seg_
 
 tda_status tda_recording_rows_dev(tda_ctx* ctx, const double* w_h0, const double* w_h1, const int* tau_seg,
                                   const double* feat_h0, const double* feat_h1, const int* seg_off, int n_seg,
-                                  double* out, void* stream)
+                                  double* out, const int* status_a, const int* status_b, int* seg_flags, void* stream)
 {
     CHECK_CTX(ctx); CHECK_NONNEG(ctx, n_seg);
     if (n_seg) { CHECK_PTR(ctx, w_h0); CHECK_PTR(ctx, w_h1); CHECK_PTR(ctx, tau_seg); CHECK_PTR(ctx, feat_h0);
                  CHECK_PTR(ctx, feat_h1); CHECK_PTR(ctx, seg_off); CHECK_PTR(ctx, out); }
-    return launch_recording_rows(ctx, w_h0, w_h1, tau_seg, feat_h0, feat_h1, seg_off, n_seg, out, (hipStream_t)stream);
+    return launch_recording_rows(ctx, w_h0, w_h1, tau_seg, feat_h0, feat_h1, seg_off, n_seg, out, status_a, status_b,
+                                 seg_flags, (hipStream_t)stream);
 }
 
 tda_status tda_features_batch_dev(tda_ctx* ctx, const double* dgm, const int* cnt, int n_dgm, int cap, double* feat,

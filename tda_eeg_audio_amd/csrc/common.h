@@ -13,6 +13,7 @@ struct tda_ctx {
     int device = 0;
     int words_dm = 2;       // H1 class capacity (x64) for distance-matrix input
     int words_cloud = 1;    // ... for point clouds
+    int retry_policy = 0;   // TDA_RETRY_*
     // host-API staging workspace (grown on demand, only by the host-pointer twins)
     void* ws = nullptr;
     size_t ws_bytes = 0;
@@ -151,7 +152,7 @@ tda_status launch_hilbert_env(tda_ctx*, const double*, int, const double*, doubl
 tda_status launch_tau(tda_ctx*, const double*, int, int, int, int*, hipStream_t);
 tda_status launch_tau_segments(tda_ctx*, const double*, const int*, int, int, int, int*, int*, hipStream_t);
 tda_status launch_recording_rows(tda_ctx*, const double*, const double*, const int*, const double*, const double*, const int*,
-                                 int, double*, hipStream_t);
+                                 int, double*, const int*, const int*, int*, hipStream_t);
 tda_status launch_features(tda_ctx*, const double*, const int*, int, int, double*, hipStream_t);
 tda_status launch_aggregate(tda_ctx*, const double*, const double*, const int*, int, double*, hipStream_t);
 tda_status launch_nanmean(tda_ctx*, const double*, const int*, int, double*, hipStream_t);

@@ -231,7 +231,8 @@ nanmean_kernel(const double* __restrict__ x, const int* __restrict__ seg_off, in
 __global__ void __launch_bounds__(64)
 recording_rows_kernel(const double* __restrict__ w0, const double* __restrict__ w1, const int* __restrict__ tau_seg,
                       const double* __restrict__ f0, const double* __restrict__ f1, const int* __restrict__ seg_off,
-                      int n_seg, double* __restrict__ out)
+                      int n_seg, double* __restrict__ out, const int* __restrict__ status_a,
+                      const int* __restrict__ status_b, int* __restrict__ seg_flags)
 {
     const int seg = blockIdx.x;
     if (seg >= n_seg) return;
@@ -260,14 +261,20 @@ recording_rows_kernel(const double* __restrict__ w0, const double* __restrict__ 
     } else if (lane == 2 * TDA_N_FEATURES + 2) {
         row[2] = (double)tau_seg[seg];
         row[3] = (double)n;
+    } else if (lane == 2 * TDA_N_FEATURES + 3 && seg_flags) {
+        int fl = 0;
+        for (int i = s0; i < s1; ++i) fl |= (status_a ? status_a[i] : 0) | (status_b ? status_b[i] : 0);
+        seg_flags[seg] = fl & TDA_WIN_CLASS_OVERFLOW;
     }
 }
 
 tda_status launch_recording_rows(tda_ctx* ctx, const double* w0, const double* w1, const int* tau_seg, const double* f0,
-                                 const double* f1, const int* seg_off, int n_seg, double* out, hipStream_t st)
+                                 const double* f1, const int* seg_off, int n_seg, double* out, const int* status_a,
+                                 const int* status_b, int* seg_flags, hipStream_t st)
 {
     if (n_seg == 0) return TDA_OK;
-    hipLaunchKernelGGL(recording_rows_kernel, dim3(n_seg), dim3(64), 0, st, w0, w1, tau_seg, f0, f1, seg_off, n_seg, out);
+    hipLaunchKernelGGL(recording_rows_kernel, dim3(n_seg), dim3(64), 0, st, w0, w1, tau_seg, f0, f1, seg_off, n_seg, out,
+                       status_a, status_b, seg_flags);
     TDA_HIP(ctx, hipGetLastError());
     return TDA_OK;
 }

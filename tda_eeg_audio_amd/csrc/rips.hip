@@ -1311,23 +1311,27 @@ tda_status launch_rips_dm(tda_ctx* ctx, const double* dm, int n_win, int n, doub
     int W = ctx->words_dm;
     // largest class capacity that still fits the 160 KiB LDS
     while (W > 1 && make_layout(n, W * 8, n * (n - 1) / 2 * 4, 256).total > LDS_MAX) W >>= 1;
+    const bool do_first = ctx->retry_policy != TDA_RETRY_ONLY, do_ladder = ctx->retry_policy != TDA_RETRY_FIRST_PASS;
+    rc = TDA_OK;
     if (n <= 64) {
-        if (W == 1) rc = launch_dm_t<1, 1>(ctx, dm, n_win, n, th, symmetrise, out, st);
+        if (!do_first) {}
+        else if (W == 1) rc = launch_dm_t<1, 1>(ctx, dm, n_win, n, th, symmetrise, out, st);
         else if (W == 2) rc = launch_dm_t<1, 2>(ctx, dm, n_win, n, th, symmetrise, out, st);
         else rc = launch_dm_t<1, 4>(ctx, dm, n_win, n, th, symmetrise, out, st);
         // widening retries: windows that ran out of class bits are redone with 2x, 4x the bits while
         // the table still fits LDS (n <= 47: 512 bits cover the theoretical maximum of 506 alive
         // classes).  A retry launch whose windows are all fine exits at once.
-        for (int Wr = 2 * W; rc == TDA_OK && Wr <= 8; Wr *= 2) {
+        for (int Wr = 2 * W; do_ladder && rc == TDA_OK && Wr <= 8; Wr *= 2) {
             if (make_layout(n, Wr * 8, n * (n - 1) / 2 * 4, 256).total > LDS_MAX) break;
             if (Wr == 2) rc = launch_dm_t<1, 2>(ctx, dm, n_win, n, th, symmetrise, out, st, 1);
             else if (Wr == 4) rc = launch_dm_t<1, 4>(ctx, dm, n_win, n, th, symmetrise, out, st, 1);
             else rc = launch_dm_t<1, 8>(ctx, dm, n_win, n, th, symmetrise, out, st, 1);
         }
     } else {
-        if (W == 1) rc = launch_dm_t<2, 1>(ctx, dm, n_win, n, th, symmetrise, out, st);
+        if (!do_first) {}
+        else if (W == 1) rc = launch_dm_t<2, 1>(ctx, dm, n_win, n, th, symmetrise, out, st);
         else rc = launch_dm_t<2, 2>(ctx, dm, n_win, n, th, symmetrise, out, st);
-        if (rc == TDA_OK && W == 1 && make_layout(n, 16, n * (n - 1) / 2 * 4, 256).total <= LDS_MAX)
+        if (do_ladder && rc == TDA_OK && W == 1 && make_layout(n, 16, n * (n - 1) / 2 * 4, 256).total <= LDS_MAX)
             rc = launch_dm_t<2, 2>(ctx, dm, n_win, n, th, symmetrise, out, st, 1);
     }
     if (rc != TDA_OK) return rc;
@@ -1381,16 +1385,18 @@ tda_status launch_rips_cloud(tda_ctx* ctx, const double* src, const int* aux, in
     // class capacity ladder: 32 bits (two workgroups per CU for 124-point clouds), then 64, then 128
     // while the table fits LDS; each wider pass only redoes the windows the previous one flagged
     const bool fits128 = make_layout(p_max, 16, p_max * dim * 8, CLOUD_NT).total <= LDS_MAX;
+    const bool do_first = ctx->retry_policy != TDA_RETRY_ONLY, do_ladder = ctx->retry_policy != TDA_RETRY_FIRST_PASS;
     int first = 1;
     if (ctx->words_cloud == 1) {
-        rc = launch_cloud_t<1, u32>(ctx, src, aux, n_win, n_t_or_pcap, dim, subsample, mode, normalise, th, p_max,
-                                    n_points, out, st, 0);
+        if (do_first)
+            rc = launch_cloud_t<1, u32>(ctx, src, aux, n_win, n_t_or_pcap, dim, subsample, mode, normalise, th, p_max,
+                                        n_points, out, st, 0);
         first = 0;
     }
-    if (rc == TDA_OK)
+    if (rc == TDA_OK && (first ? do_first : do_ladder))
         rc = launch_cloud_t<1, u64>(ctx, src, aux, n_win, n_t_or_pcap, dim, subsample, mode, normalise, th, p_max,
                                     n_points, out, st, first ? 0 : 1);
-    if (rc == TDA_OK && fits128)
+    if (do_ladder && rc == TDA_OK && fits128)
         rc = launch_cloud_t<2, u64>(ctx, src, aux, n_win, n_t_or_pcap, dim, subsample, mode, normalise, th, p_max,
                                     n_points, out, st, 1);
     if (rc != TDA_OK) return rc;

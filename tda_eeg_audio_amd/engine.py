@@ -318,8 +318,10 @@ def tau_segments_dev(win_t, seg_off_t, max_lag=None, tau_seg_t=None, tau_win_t=N
     return tau_seg_t
 
 
-def recording_rows_dev(w0_t, w1_t, tau_seg_t, fe0_t, fe1_t, seg_off_t, out_t=None, ctx=None):
-    """(n_seg, 48) rows [nanmean W_H0, nanmean W_H1, tau, n_windows, 44 aggregated features] in one launch."""
+def recording_rows_dev(w0_t, w1_t, tau_seg_t, fe0_t, fe1_t, seg_off_t, out_t=None, status_a=None, status_b=None,
+                       seg_flags=None, ctx=None):
+    """(n_seg, 48) rows [nanmean W_H0, nanmean W_H1, tau, n_windows, 44 aggregated features] in one launch.
+    seg_flags (optional, (n_seg,) int32): per group, OR of the class-overflow bits of the two status arrays."""
     import torch
     ctx = ctx or get_ctx()
     n_seg = seg_off_t.numel() - 1
@@ -327,7 +329,8 @@ def recording_rows_dev(w0_t, w1_t, tau_seg_t, fe0_t, fe1_t, seg_off_t, out_t=Non
         out_t = torch.empty((n_seg, 4 + 4 * _lib.N_FEATURES), dtype=torch.float64, device=w0_t.device)
     assert out_t.is_contiguous()
     ctx.check(ctx.lib.tda_recording_rows_dev(ctx.h, _tp(w0_t), _tp(w1_t), _tp(tau_seg_t), _tp(fe0_t), _tp(fe1_t),
-                                             _tp(seg_off_t), n_seg, _tp(out_t), _stream()))
+                                             _tp(seg_off_t), n_seg, _tp(out_t), _tp(status_a), _tp(status_b),
+                                             _tp(seg_flags), _stream()))
     return out_t
 
 

@@ -37,6 +37,8 @@ class Workspace:
         self.aud = engine.DeviceDiagrams(n_win, 128, h1_cap, device)
         self.tau_seg = torch.empty(self.n_seg, dtype=torch.int32, device=device)
         self.tau_win = torch.empty(n_win, dtype=torch.int32, device=device)
+        self.seg_flags = torch.zeros(self.n_seg, dtype=torch.int32, device=device)     # class-overflow bits per group
+        self.flags_host = torch.zeros(self.n_seg, dtype=torch.int32).pin_memory()
         self.w0 = torch.empty(n_win, **f64); self.w1 = torch.empty(n_win, **f64)
         self.ws0 = torch.empty(n_win, dtype=torch.int32, device=device)
         self.ws1 = torch.empty(n_win, dtype=torch.int32, device=device)
@@ -49,10 +51,26 @@ class Workspace:
         self.overlap = os.environ.get("TDA_OVERLAP", "1") != "0"     # EEG chain on a side stream
 
 
-def run_step(eeg_win, audio_win, ws, ctx=None, max_lag=125, timers=None):
+def run_step(eeg_win, audio_win, ws, ctx=None, max_lag=125, timers=None, retry="auto"):
     """One pass of the hot path over the batch.  eeg_win (n_win,47,250) f64, audio_win (n_win,250)
     f64, both resident in HBM.  Returns ws.result (n_seg, 48).  `timers`: optional dict of
-    (start,end) torch.cuda.Event pairs per stage, recorded on the launch stream."""
+    (start,end) torch.cuda.Event pairs per stage, recorded on the launch stream.
+    retry="auto": every Rips call launches its widening passes (exact by itself).  retry="first": first passes
+    only; the class-overflow bits of the batch are copied to ws.flags_host (pinned) at the end of the step and
+    the caller re-runs the step with retry="auto" if any is set (pipeline.Lanes does)."""
+    import torch
+    from . import _lib
+    ctx = ctx or _lib.get_ctx()
+    if retry == "first":
+        ctx.set_retry_policy(ctx.RETRY_FIRST_PASS)
+    try:
+        return _run_step(eeg_win, audio_win, ws, ctx, max_lag, timers, retry)
+    finally:
+        if retry == "first":
+            ctx.set_retry_policy(ctx.RETRY_AUTO)
+
+
+def _run_step(eeg_win, audio_win, ws, ctx, max_lag, timers, retry):
     import torch
 
     def stage(name, fn):
@@ -93,8 +111,24 @@ def run_step(eeg_win, audio_win, ws, ctx=None, max_lag=125, timers=None):
     # per recording-band rows: nanmean of the distances (cmp:117-118), tau, window count, mean/std of the EEG
     # features (v2:429-436) -- one launch
     stage("reduce", lambda: engine.recording_rows_dev(ws.w0, ws.w1, ws.tau_seg, ws.fe0, ws.fe1, ws.seg_off, ws.result,
-                                                      ctx=ctx))
+                                                      ws.eeg.status, ws.aud.status, ws.seg_flags, ctx=ctx))
+    if retry == "first":
+        ws.flags_host.copy_(ws.seg_flags, non_blocking=True)
     return ws.result
+
+
+class Batch:
+    """Handle of a submitted batch: `result()` waits for it, repairs it if a window ran out of class bits, runs the
+    `post` callback and returns its value (or the lane's result rows, valid until the lane is used again)."""
+
+    def __init__(self, lanes, lane, inputs, post, event):
+        self.lanes, self.lane, self.inputs, self.post, self.event = lanes, lane, inputs, post, event
+        self.done, self.value, self.repaired = False, None, False
+
+    def result(self):
+        if not self.done:
+            self.lanes._finalize(self.lane)
+        return self.value
 
 
 class Lanes:
@@ -102,63 +136,94 @@ class Lanes:
     independent, cmp:77-122 runs them one after the other) go to alternating lanes, so that the
     thin tail of one batch's grids -- 710 workgroups on 256 CUs is 1.4 rounds of the audio Rips
     kernel -- is filled by the head of the next batch instead of leaving CUs idle.  Every lane owns
-    its buffers; results of a lane are complete when its stream has drained (`drain`).
+    its buffers.
 
-    graph=True: the ~25 launches of a step are captured once per (lane, input buffers) into a HIP graph
-    and replayed afterwards, which takes the per-step host work from ~0.35 ms to ~0.07 ms.  Inputs are
-    baked in by address, so feed the lanes from a fixed ring of device buffers."""
+    graph=True: the launches of a step are captured once per (lane, input buffers) into a HIP graph
+    and replayed afterwards, which takes the per-step host work from ~0.35 ms to ~0.06 ms.  Inputs are
+    baked in by address, so feed the lanes from a fixed ring of device buffers.
 
-    def __init__(self, depth, n_win, seg_off, device, graph=False, **kw):
+    defer_retries=True: a step launches only the first pass of the two Rips stages.  Their widening
+    passes redo just the windows that ran out of class bits -- rarely any -- but each is a launch
+    that needs a large share of a CU before it can even look, and on a full GPU that stalls the lane
+    (5-6 % of the throughput).  Instead the overflow bits of the batch travel to pinned host memory
+    with the step; when the lane comes up again (`depth` batches later, so the wait is normally
+    over) they are inspected, the batch is re-run with the full ladder if any is set, and only then
+    is it published through `post` / `Batch.result()` (verify, then publish)."""
+
+    def __init__(self, depth, n_win, seg_off, device, graph=False, defer_retries=True, **kw):
         import torch
         self.depth = max(1, int(depth))
         self.ws = [Workspace(n_win, seg_off, device, **kw) for _ in range(self.depth)]
         self.streams = [torch.cuda.Stream(device=device) for _ in range(self.depth)]
         self.k = 0
         self.graph = bool(graph)
+        self.defer = bool(defer_retries)
         self.graphs = {}
+        self.pending = [None] * self.depth
+        self.repairs = 0
         self.before_step = None      # optional callable(lane index): runs before a step is launched or captured
 
+    def _finalize(self, i):
+        import torch
+        b = self.pending[i]
+        if b is None:
+            return
+        self.pending[i] = None
+        st, ws = self.streams[i], self.ws[i]
+        b.event.synchronize()
+        eeg_win, audio_win, ctx, max_lag = b.inputs
+        with torch.cuda.stream(st):
+            if self.defer and bool(ws.flags_host.any()):
+                run_step(eeg_win, audio_win, ws, ctx=ctx, max_lag=max_lag, retry="auto")     # rare: full ladder
+                b.repaired = True
+                self.repairs += 1
+            b.value = b.post(ws.result) if b.post is not None else ws.result
+        b.done = True
+
     def submit(self, eeg_win, audio_win, ctx=None, max_lag=125, timers=None, post=None, sync_inputs=True):
-        """Enqueue one step on the next lane; returns that lane's result tensor (valid until the lane
-        is used again; wait with `drain` or on the lane's stream).  `post(result)` runs on the lane's
-        stream too (e.g. the all-gather of the result rows).  `timers` forces an eager (uncaptured) step.
+        """Enqueue one step on the next lane and return its Batch handle.  The batch that used the lane before
+        is finalized first (see class docstring).  `post(result)` runs on the lane's stream when the batch is
+        finalized (e.g. the all-gather of the result rows).  `timers` forces an eager (uncaptured) step.
         sync_inputs=False skips the wait on the caller's stream (inputs already complete in HBM)."""
         import torch
         i = self.k % self.depth
         self.k += 1
-        st = self.streams[i]
+        self._finalize(i)
+        st, ws = self.streams[i], self.ws[i]
         if sync_inputs:                                      # inputs produced on the caller's stream; pass False when
             st.wait_stream(torch.cuda.current_stream())     # they are resident and unchanged (costs ~0.07 ms per step)
-        ws = self.ws[i]
+        retry = "first" if self.defer else "auto"
         key = (i, eeg_win.data_ptr(), audio_win.data_ptr(), int(max_lag), id(ctx))
         if self.graph and timers is None:
             g = self.graphs.get(key)
             if g is None:
                 with torch.cuda.stream(st):                  # eager once: lazy initialisations stay out of the capture
-                    run_step(eeg_win, audio_win, ws, ctx=ctx, max_lag=max_lag)
+                    run_step(eeg_win, audio_win, ws, ctx=ctx, max_lag=max_lag, retry=retry)
                 st.synchronize()
                 if self.before_step is not None:
                     self.before_step(i)
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g, stream=st):
-                    run_step(eeg_win, audio_win, ws, ctx=ctx, max_lag=max_lag)
+                    run_step(eeg_win, audio_win, ws, ctx=ctx, max_lag=max_lag, retry=retry)
                 self.graphs[key] = g
             with torch.cuda.stream(st):
                 g.replay()
-                res = ws.result
-                if post is not None:
-                    res = post(res)
-            return res
-        if self.before_step is not None:
-            self.before_step(i)
-        with torch.cuda.stream(st):
-            res = run_step(eeg_win, audio_win, ws, ctx=ctx, max_lag=max_lag, timers=timers)
-            if post is not None:
-                res = post(res)
-        return res
+        else:
+            if self.before_step is not None:
+                self.before_step(i)
+            with torch.cuda.stream(st):
+                run_step(eeg_win, audio_win, ws, ctx=ctx, max_lag=max_lag, timers=timers, retry=retry)
+        ev = torch.cuda.Event()
+        ev.record(st)
+        b = Batch(self, i, (eeg_win, audio_win, ctx, max_lag), post, ev)
+        self.pending[i] = b
+        return b
 
     def drain(self):
+        """Finalize every batch still in flight and make the caller's stream wait for the lanes."""
         import torch
+        for i in range(self.depth):
+            self._finalize(i)
         cur = torch.cuda.current_stream()
         for st in self.streams:
             cur.wait_stream(st)

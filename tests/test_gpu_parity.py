@@ -438,7 +438,8 @@ def test_pipeline_step_vs_oracle_and_lanes(ctx):
     lanes.drain()
     torch.cuda.synchronize()
     for k in range(5):
-        assert np.array_equal(got[k].cpu().numpy(), serial[k], equal_nan=True), k
+        assert np.array_equal(got[k].result().cpu().numpy(), serial[k], equal_nan=True), k
+    assert lanes.repairs == 0
     # the same through captured HIP graphs (one per lane and input buffer pair), replayed twice
     glanes = pipeline.Lanes(2, n_win, seg_off, dev, graph=True)
     for rnd in range(2):
@@ -446,8 +447,46 @@ def test_pipeline_step_vs_oracle_and_lanes(ctx):
         glanes.drain()
         torch.cuda.synchronize()
         for k in range(4):
-            assert np.array_equal(got[k].cpu().numpy(), serial[k], equal_nan=True), (rnd, k)
+            assert np.array_equal(got[k].result().cpu().numpy(), serial[k], equal_nan=True), (rnd, k)
     assert len(glanes.graphs) == 4
+
+
+def test_lanes_verify_then_publish_repairs_overflowing_batches(ctx):
+    """Deferred retries: with 64 class bits white-noise EEG windows overflow the first pass; the lanes must notice
+    (flags in pinned memory), re-run those batches with the widening passes and publish the exact rows."""
+    import torch
+    from tda_eeg_audio_amd import pipeline
+    dev = torch.device("cuda", 0)
+    n_win, wpr = 30, 15
+    seg_off = np.array([0, 15, 30], np.int32)
+    batches = []
+    for k in range(4):
+        kind = "white" if k % 2 == 0 else "latent"
+        eeg = synth.eeg_windows(n_win, seed=900 + k, windows_per_recording=wpr, kind=kind)
+        aud = synth.audio_windows(n_win, "beta", seed=950 + k)
+        batches.append((torch.from_numpy(eeg).to(dev), torch.from_numpy(aud).to(dev)))
+    ctx.set_class_words(1, 1)
+    try:
+        ws = pipeline.Workspace(n_win, seg_off, dev)
+        serial = []
+        for eeg_t, aud_t in batches:
+            serial.append(pipeline.run_step(eeg_t, aud_t, ws, ctx=ctx, retry="auto").cpu().numpy().copy())
+            assert int(ws.eeg.status.max()) == 0
+        # the first pass alone does flag windows of the white-noise batches
+        pipeline.run_step(batches[0][0], batches[0][1], ws, ctx=ctx, retry="first")
+        torch.cuda.synchronize()
+        assert int((ws.eeg.status & 2).max()) == 2 and bool(ws.flags_host.any())
+        for graph in (False, True):
+            lanes = pipeline.Lanes(2, n_win, seg_off, dev, graph=graph, defer_retries=True)
+            got = [lanes.submit(e, a, ctx=ctx, post=lambda r: r.clone()) for e, a in batches]
+            lanes.drain()
+            torch.cuda.synchronize()
+            assert lanes.repairs >= 2, lanes.repairs
+            for k in range(4):
+                assert got[k].repaired == (k % 2 == 0) or got[k].repaired, k
+                assert np.array_equal(got[k].result().cpu().numpy(), serial[k], equal_nan=True), (graph, k)
+    finally:
+        ctx.set_class_words(2, 1)
 
 
 def test_fused_row_kernels_equal_their_parts(ctx):

@@ -29,10 +29,12 @@ def run(label, stub, lanes=3, steps=100):
     L = pipeline.Lanes(lanes, n_win, seg, dev)
     for _ in range(2 * lanes):
         L.submit(eeg_t, aud_t, ctx=ctx)          # real data in every buffer first
+    L.drain()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(steps):
         L.submit(eeg_t, aud_t, ctx=ctx)
+    L.drain()
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
     print(f"{label:58s} {dt * 1e3:.4f} ms/step")
