@@ -78,6 +78,10 @@ def main():
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     ctx = _lib.get_ctx(local)
+    # first-pass class capacity: 64 bits for the EEG matrices (library default 128), 32 for the audio clouds.  No window
+    # of this workload needs more (tools/overflow_rate.py); any that did would be caught and repaired by the lanes.
+    if not os.environ.get("TDA_CLASS_WORDS"):
+        ctx.set_class_words(1, 1)
 
     n_win = args.windows
     wpr = args.windows_per_recording
@@ -183,7 +187,8 @@ def main():
                                    f"({wpr} windows) reductions" + ("; one all-gather of result rows" if world > 1 else ""),
                        "windows_per_gpu": n_win, "thresh": 2.0, "parallelism": f"recordings sharded x{world}",
                        "batches_in_flight": lanes.depth, "hip_graph": lanes.graph,
-                       "deferred_retries": lanes.defer, "batches_repaired": lanes.repairs},
+                       "deferred_retries": lanes.defer, "batches_repaired": lanes.repairs,
+                       "first_pass_class_bits": {"eeg": 64 if not os.environ.get("TDA_CLASS_WORDS") else None, "audio": 32}},
             "stage_ms": {s: round(v, 4) for s, v in stage_ms.items()},       # eager warm-up steps, overlapping lanes
             "host_loop_ms_per_step": round(t_enq / args.steps * 1e3, 4),   # includes the wait for the batch `lanes` steps back
             "roofline": {"bound": "hbm", "kernel": "rips_cloud_kernel<512, 1, unsigned int> (stage rips_audio)",

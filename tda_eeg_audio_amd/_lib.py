@@ -123,6 +123,11 @@ class Context:
                            "-- the HIP path needs a visible MI355X; there is no CPU fallback")
         self.h = h
         self.device = int(device)
+        # first-pass class capacity (x64 bits) of the Rips kernels, e.g. TDA_CLASS_WORDS=1,1 (dm, cloud)
+        cw = os.environ.get("TDA_CLASS_WORDS")
+        if cw:
+            dm, cloud = (int(x) for x in cw.split(","))
+            self.set_class_words(dm, cloud)
 
     def check(self, rc):
         if rc != 0:
