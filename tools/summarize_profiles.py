@@ -50,7 +50,7 @@ for d, ctr in (("prof_fetch", "FETCH_SIZE"), ("prof_write", "WRITE_SIZE")):
 json.dump(pmc, open(os.path.join(out, f"{tag}_pmc_summary.json"), "w"), indent=1)
 
 STAGE_KERNEL = {
-    "corr_dist": "corr_dist_kernel", "rips_eeg": "rips_dm_kernel<256, 1, 2", "rips_audio": "rips_cloud_kernel<512, 1, unsigned int",
+    "corr_dist": "corr_dist_kernel", "rips_eeg": "rips_dm_kernel<256, 1, 1", "rips_audio": "rips_cloud_kernel<512, 1, unsigned int",
     "wasserstein_h0": "wasserstein_kernel<2", "wasserstein_h1": "wasserstein_kernel<4", "tau": "tau_kernel",
 }
 # gfx950: FETCH_SIZE reports half of the bytes of wide coalesced streaming reads (MI355X_MICROARCH.md).  corr_dist reads
