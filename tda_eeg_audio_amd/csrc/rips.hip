@@ -1051,9 +1051,9 @@ struct KeyFromPts {
 // class vector) run a small grid that strides over the windows and only redoes the ones the previous
 // pass flagged, so a retry with nothing to do costs a few microseconds instead of n_win LDS-heavy
 // workgroup launches.
-// 128 classes or fewer: four 256-thread workgroups per CU = 4 waves per SIMD (128 VGPRs)
+// 64 classes: five 256-thread workgroups per CU = 5 waves per SIMD (102 VGPRs); 128 classes: four (128 VGPRs)
 template <int NT, int NVW, int W, typename WT>
-__global__ void __launch_bounds__(NT, W <= 2 ? 4 : 1)
+__global__ void __launch_bounds__(NT, W == 1 ? 5 : (W == 2 ? 4 : 1))
 rips_dm_kernel(const double* __restrict__ dm, int n_win, int n, float thresh, int symmetrise, RipsLayout L,
                RipsOut out, int retry_only)
 {
