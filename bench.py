@@ -127,10 +127,22 @@ def main():
         out = step(timers)
         ev_log.append(timers)
     cur_events[0] = None
-    for _ in range(lanes.depth):
-        out = step()
-    lanes.drain()
-    torch.cuda.synchronize()
+    try:
+        for _ in range(lanes.depth):
+            out = step()
+        lanes.drain()
+        torch.cuda.synchronize()
+    except Exception as e:                      # graph capture refused on this stack: same steps, launched eagerly
+        if not lanes.graph:
+            raise
+        print(f"bench: HIP graph capture failed ({type(e).__name__}: {e}); falling back to eager launches", file=sys.stderr)
+        torch.cuda.synchronize()
+        lanes = pipeline.Lanes(args.lanes, n_win, seg_off, device, graph=False, defer_retries=not args.no_defer)
+        lanes.before_step = arm
+        for _ in range(lanes.depth):
+            out = step()
+        lanes.drain()
+        torch.cuda.synchronize()
     for ws in lanes.ws:
         if not bool(((ws.eeg.status == 0) & ((ws.aud.status & ~4) == 0) & (ws.ws0 == 0) & (ws.ws1 == 0)).all()):
             raise SystemExit("bench: a window reported a non-zero status (overflow / not converged)")
