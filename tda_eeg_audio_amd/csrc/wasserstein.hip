@@ -405,9 +405,12 @@ tda_status launch_wasserstein(tda_ctx* ctx, const double* dgm_a, const int* cnt_
     if (max_cols > 512) TDA_FAIL(ctx, TDA_ERR_UNSUPPORTED, "diagrams with more than 512 rows are not supported");
     const size_t vec_bytes = (size_t)(4 * max_rows + 3 * max_cols + ((max_cols + 1) >> 1)) * 8;
     const size_t mat_bytes = (size_t)max_rows * max_cols * 8;
-    // LDS budget for the per-pair cost matrix: whole matrix if small, else 48 KB (6144 entries:
-    // enough for 46 x 123 H0 pairs); pairs that do not fit evaluate costs on the fly
-    size_t mat_budget = mat_bytes <= 48 * 1024 ? mat_bytes : 48 * 1024;
+    // LDS budget for the per-pair cost matrix: whole matrix if small, else 16 KB (2048 entries: a 45 x 45 H1 pair;
+    // H0 pairs have equal births and take the 1-D path without a matrix); pairs that do not fit evaluate costs on
+    // the fly.  A small footprint matters more than the rare big pair: the workgroups of this kernel (one wave
+    // each) have to find room next to the Rips kernels of the other batches in flight.
+    const size_t cap_budget = 16 * 1024;
+    size_t mat_budget = mat_bytes <= cap_budget ? mat_bytes : cap_budget;
     const int mat_entries = (int)(mat_budget / 8);
     const size_t lds = vec_bytes + mat_budget;
 #define WS_LAUNCH(CWV)                                                                                         \
