@@ -102,7 +102,7 @@ int main()
         int wc_khz = 0; hipDeviceGetAttribute(&wc_khz, hipDeviceAttributeWallClockRate, 0);
         int clk_khz = 0; hipDeviceGetAttribute(&clk_khz, hipDeviceAttributeClockRate, 0);
         printf("clock64 ticks=%llu wall_clock64 ticks=%llu (wall clock rate %d kHz, device clock rate %d kHz) -> clock64 runs at %.1f MHz\n",
-               h[0], h[1], wc_khz, clk_khz, (double)h[0] / ((double)h[1] / wc_khz * 1e3) / 1e6 * 1e3 / 1e3);
+               h[0], h[1], wc_khz, clk_khz, (double)h[0] / (double)h[1] * (double)wc_khz / 1e3);
     }
     RUN("mfma_f64_16x16x4, 1 wave, dependent chain", mfma_chain<1>, 64, 1);
     RUN("mfma_f64_16x16x4, 1 wave, 2 accumulators", mfma_chain<2>, 64, 2);
