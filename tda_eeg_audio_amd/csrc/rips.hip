@@ -21,8 +21,10 @@
 //         edge of this chunk, and those few candidates (bit rows of the chunk's own edges) are
 //         confirmed with two rank look-ups -- no sequential adjacency state inside a chunk;
 //      b. edges with M_r = 0 are the only candidates for negative (spanning-forest) edges: wave 0
-//         walks them in rank order with the component labels in registers and decides
+//         walks them in rank order with the component labels in registers and leaves one bit each,
 //                                      merge -> H0 death at |e|   /   else -> a new H1 class is born;
+//         the H0 rows, the class bits of the births and their table entries are then allocated by
+//         prefix sums over ballots and written by the lanes that own the edges;
 //      c. every other edge is killed at once by a triangle (a,b,v*), v* preferably a common
 //         neighbour that predates the chunk:  psi[e] = psi[a,v*] ^ psi[b,v*], where psi[edge] in LDS
 //         is the class of the cycle "edge + forest path" as a bit vector over the alive H1 classes;
@@ -40,7 +42,8 @@
 //  P4  rows are written as float64 (float32-exact) pairs: H0 ascending death then the essential
 //      rows; H1 rows are ordered by a second tiny kernel (descending birth).
 //
-// LDS per workgroup: 36 KB (n = 47, 128 classes) .. 80 KB (n = 124 point cloud, 32-bit classes).
+// LDS per workgroup: 30 KB (n = 47, 64 classes), 39 KB (128 classes) .. 78.5 KB (n = 124 point cloud, 32-bit classes).
+// Class capacity ladder: a first pass, then widening passes that redo only flagged windows (tda_set_retry_policy).
 // No MFMA: this is irregular integer work; the roofline that binds it is LDS latency/issue.
 #include "common.h"
 
