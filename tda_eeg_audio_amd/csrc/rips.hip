@@ -42,7 +42,7 @@
 //  P4  rows are written as float64 (float32-exact) pairs: H0 ascending death then the essential
 //      rows; H1 rows are ordered by a second tiny kernel (descending birth).
 //
-// LDS per workgroup: 30 KB (n = 47, 64 classes), 39 KB (128 classes) .. 78.5 KB (n = 124 point cloud, 32-bit classes).
+// LDS per workgroup: 30 KB (n = 47, 64 classes), 36 KB (128 classes) .. 77.5 KB (n = 124 point cloud, 32-bit classes).
 // Class capacity ladder: a first pass, then widening passes that redo only flagged windows (tda_set_retry_policy).
 // No MFMA: this is irregular integer work; the roofline that binds it is LDS latency/issue.
 #include "common.h"
