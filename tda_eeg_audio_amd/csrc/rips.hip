@@ -46,6 +46,7 @@
 // Class capacity ladder: a first pass, then widening passes that redo only flagged windows (tda_set_retry_policy).
 // No MFMA: this is irregular integer work; the roofline that binds it is LDS latency/issue.
 #include "common.h"
+#include <stdlib.h>
 
 #define NT_MAX 512            // largest workgroup (point-cloud flavour); distance-matrix flavour uses 256
 #define RANK_NONE 0x7fffu
@@ -1178,8 +1179,11 @@ __device__ void rips_cloud_window(unsigned char* smem, const int win, const doub
 }
 
 // two 512-thread workgroups per CU = 4 waves per SIMD (second launch-bound parameter of hip-clang): 128 VGPRs
+#ifndef CLOUD_WAVES
+#define CLOUD_WAVES 4
+#endif
 template <int NT, int W, typename WT>
-__global__ void __launch_bounds__(NT, 4)
+__global__ void __launch_bounds__(NT, CLOUD_WAVES)
 rips_cloud_kernel(const double* __restrict__ src, const int* __restrict__ tau_or_npts, int n_win,
                   int n_t_or_pcap, int dim, int subsample, int mode, int normalise, float thresh,
                   RipsLayout L, int p_max, int* __restrict__ n_points, RipsOut out, int retry_only,
@@ -1380,6 +1384,9 @@ tda_status launch_rips_cloud(tda_ctx* ctx, const double* src, const int* aux, in
         p_max = n_t_or_pcap;
     }
     if (p_max > TDA_MAX_POINTS) p_max = TDA_MAX_POINTS;   // larger clouds are flagged per window
+#ifdef TDA_EXPERIMENT
+    if (getenv("TDA_EXP_PMAX")) p_max = atoi(getenv("TDA_EXP_PMAX"));   // co-residency probe: smaller LDS layout
+#endif
     if (p_max < 3) p_max = 3;
     if (h0_cap < p_max) TDA_FAIL(ctx, TDA_ERR_INVALID, "h0_cap must be >= max points per cloud");
     RipsOut out{h0, h0_cap, h0_cnt, h1, h1_cap, h1_cnt, status};
