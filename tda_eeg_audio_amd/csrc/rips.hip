@@ -146,47 +146,85 @@ __device__ __forceinline__ int edge_row(int e)
     return a;
 }
 
-// in-LDS bitonic sort of npad (power of two >= 4*NT... any >= 4) u64 keys by the whole workgroup.
-// Two butterfly stages (j and j/2) are fused per pass: each thread owns the 4 elements
-// {b, b+j/2, b+j, b+3j/2}, so every pass costs one LDS round trip instead of two.
-__device__ __forceinline__ void cex(u64& x, u64& y, bool up)
+// ---------------------------------------------------------------------------------
+// P1: stable LSD radix sort of the edges by their float32 length, in LDS, by the whole workgroup.
+// The keys stay where they are (key32[e], e = flat edge index tri2(a)+b); what moves is the 16-bit
+// edge (a << 8 | b), ping-ponging between two arrays, four key bits per pass.  The edges start in
+// flat-index order and every pass is stable, so equal lengths keep (a,b) order: the same total order
+// as sorting (key << 16 | a << 8 | b).  Thread t owns the B consecutive positions [t B, (t+1) B):
+//   count   16 digit counters per thread (8 bits each, two u64 registers) -> cnt[digit][t]
+//   scan    exclusive prefix sum over cnt in (digit-major, thread-minor) order = first destination of every
+//           (digit, thread); 16 consecutive entries per thread, wave scan on the DPP network
+//   scatter positions again in order: destination = cnt[digit][t] + (equal digits seen before in this thread)
+// A pass whose digit is the same for every edge (the top bits of lengths in (0, 2]) costs one barrier.
+// ~8 k compare-free LDS accesses per thread for 7,626 edges, where the bitonic network needed 373 k 64-bit
+// compare-exchanges (VALU bound).
+// ---------------------------------------------------------------------------------
+__device__ __forceinline__ int wave_incl_scan_i32(int v)
 {
-    const u64 lo = x < y ? x : y, hi = x < y ? y : x;
-    x = up ? lo : hi;
-    y = up ? hi : lo;
+#define TDA_DPP_ADD_(CTRL, RM) v += __builtin_amdgcn_update_dpp(0, v, CTRL, RM, 0xF, true)
+    TDA_DPP_ADD_(0x111, 0xF);     // row_shr:1
+    TDA_DPP_ADD_(0x112, 0xF);     // row_shr:2
+    TDA_DPP_ADD_(0x114, 0xF);     // row_shr:4
+    TDA_DPP_ADD_(0x118, 0xF);     // row_shr:8
+    TDA_DPP_ADD_(0x142, 0xA);     // row_bcast:15 -> rows 1, 3
+    TDA_DPP_ADD_(0x143, 0xC);     // row_bcast:31 -> rows 2, 3
+#undef TDA_DPP_ADD_
+    return v;
 }
+__device__ __forceinline__ int edge_flat(u32 pk) { return tri2((int)(pk >> 8)) + (int)(pk & 255u); }
+
+// key32: E keys; ia: E edges in flat order on entry; ib: second array; cnt: 16 * NT u16; wsum: NT/64 ints.
+// Returns the array that holds the sorted edges.
 template <int NT>
-__device__ void bitonic_sort_lds(u64* S, int npad)
+__device__ u16* radix_sort_lds(const u32* key32, u16* ia, u16* ib, u16* cnt, int* wsum, int E)
 {
-    const int tid = threadIdx.x;
-    for (int k = 2; k <= npad; k <<= 1) {
-        int j = k >> 1;
-        while (j >= 2) {
-            const int jh = j >> 1;
-#pragma unroll 4
-            for (int t = tid; t < (npad >> 2); t += NT) {
-                const int b = ((t & ~(jh - 1)) << 2) | (t & (jh - 1));
-                const bool up = (b & k) == 0;
-                u64 e0 = S[b], e1 = S[b + jh], e2 = S[b + j], e3 = S[b + j + jh];
-                cex(e0, e2, up); cex(e1, e3, up);
-                cex(e0, e1, up); cex(e2, e3, up);
-                S[b] = e0; S[b + jh] = e1; S[b + j] = e2; S[b + j + jh] = e3;
-            }
-            __syncthreads();
-            j >>= 2;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int B = (E + NT - 1) / NT;                  // positions per thread (<= 32)
+    const int p0 = tid * B, p1 = (p0 + B < E) ? p0 + B : E;
+    u16* cur = ia;
+    u16* nxt = ib;
+    if (E < 2) return cur;
+    for (int shift = 0; shift < 32; shift += 4) {
+        // ---- count ----
+        u64 c0 = 0ull, c1 = 0ull;                     // digits 0..7 / 8..15, 8 bits each
+        const int dfirst = (int)((key32[edge_flat(cur[0])] >> shift) & 15u);
+        bool same = true;
+        for (int p = p0; p < p1; ++p) {
+            const int d = (int)((key32[edge_flat(cur[p])] >> shift) & 15u);
+            same = same && d == dfirst;
+            const u64 one = 1ull << (8 * (d & 7));
+            if (d < 8) c0 += one; else c1 += one;
         }
-        if (j == 1) {
-#pragma unroll 4
-            for (int t = tid; t < (npad >> 1); t += NT) {
-                const int i = t << 1;
-                const bool up = (i & k) == 0;
-                u64 x = S[i], y = S[i + 1];
-                cex(x, y, up);
-                S[i] = x; S[i + 1] = y;
-            }
-            __syncthreads();
+#pragma unroll
+        for (int d = 0; d < 16; ++d) cnt[d * NT + tid] = (u16)(((d < 8 ? c0 : c1) >> (8 * (d & 7))) & 255ull);
+        if (__syncthreads_and(same ? 1 : 0)) continue;           // every edge has this digit: nothing moves
+        // ---- scan: entries [16 t, 16 t + 16) of the (digit-major, thread-minor) table ----
+        int loc[16], s = 0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) { loc[k] = s; s += (int)cnt[16 * tid + k]; }
+        const int incl = wave_incl_scan_i32(s);
+        if (lane == 63) wsum[wave] = incl;
+        __syncthreads();
+        int basep = incl - s;
+        for (int w = 0; w < wave; ++w) basep += wsum[w];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) cnt[16 * tid + k] = (u16)(basep + loc[k]);
+        __syncthreads();
+        // ---- scatter ----
+        c0 = 0ull; c1 = 0ull;
+        for (int p = p0; p < p1; ++p) {
+            const u32 pk = cur[p];
+            const int d = (int)((key32[edge_flat(pk)] >> shift) & 15u);
+            const int sh = 8 * (d & 7);
+            const int seen = (int)(((d < 8 ? c0 : c1) >> sh) & 255ull);
+            if (d < 8) c0 += 1ull << sh; else c1 += 1ull << sh;
+            nxt[(int)cnt[d * NT + tid] + seen] = (u16)pk;
         }
+        __syncthreads();
+        u16* t_ = cur; cur = nxt; nxt = t_;
     }
+    return cur;
 }
 
 // Scan the remaining triangles (a,b,v), v in one 32-bit mask word (vertices vbase..vbase+31), four
@@ -233,14 +271,14 @@ __device__ __forceinline__ bool scan_word(u32& mw, const int vbase, const Psi<W,
 // vmax[v] (u32 sortable keys, LDS) must hold max_u key(v,u) on entry.  Returns the number of edges
 // whose key is <= the effective threshold (workgroup-uniform) .
 template <int NT>
-__device__ int count_effective_edges(const u64* S, int E, int n, u32 tkey, const u32* vmax, int* red)
+__device__ int count_effective_edges(const u32* key32, int E, int n, u32 tkey, const u32* vmax, int* red)
 {
     const int tid = threadIdx.x;
     u32 renc = 0xffffffffu;
     for (int v = 0; v < n; ++v) { const u32 m = vmax[v]; renc = m < renc ? m : renc; }
     const u32 teff = renc < tkey ? renc : tkey;
     int ev = 0;
-    for (int e = tid; e < E; e += NT) ev += ((u32)(S[e] >> 16) <= teff) ? 1 : 0;
+    for (int e = tid; e < E; e += NT) ev += (key32[e] <= teff) ? 1 : 0;
     if (tid == 0) *red = 0;
     __syncthreads();
 #pragma unroll
@@ -257,7 +295,8 @@ struct RipsOut {
 };
 
 struct RipsLayout {
-    int off_rank, off_ord, off_aux, off_misc;   // psi (and the sort array) start at 0
+    int off_ia, off_ib;                         // sort phase: keys at 0, then the two edge arrays
+    int off_rank, off_ord, off_aux, off_misc;   // sweep phase: psi at 0, rank, ord; then aux and misc
     int total;
 };
 
@@ -267,6 +306,7 @@ struct RipsLayout {
 #define MISC_WV (512 + 128)                                  // 64 B scratch
 #define MISC_MIN (512 + 192)                                 // u32[4]: reductions; list count / earliest key
 #define MISC_DONE (512 + 208)                                // u8 done[NT_MAX]
+#define MISC_SORTCNT (512 + 224)                             // sort phase only: u16 cnt[16 * NT] (over the sweep's part)
 #define MISC_SHARED (MISC_DONE + NT_MAX)                     // SweepShared (96 B)
 #define MISC_CKEY (MISC_SHARED + 96)                         // float ckey[NT_MAX]: lengths of this chunk's candidate edges
 #define MISC_LIST MISC_CKEY                                  // phase d reuses ckey + the tail: triangle list, then image table
@@ -925,36 +965,40 @@ __device__ void rips_sweep(int n, int E, int Ev, const u16* rank, const u16* ord
 }
 
 // rank (triangular: rank[tri2(a) + b] = position of edge (a,b), a > b; RANK_NONE beyond the effective
-// threshold), ord (ord[e] = a << 8 | b) and, for distance matrices, skey from the sorted composites.
-// STAGE: the rank/ord region overlaps the sorted array (psi narrower than 8 B per edge), so every
-// thread first pulls its <= 16 entries into registers.
+// threshold), ord (ord[r] = a << 8 | b) and, for distance matrices, skey[r] from the sorted edge array.
+// rank / ord (and psi) overlay the sort arrays, so every thread first pulls its positions into registers.
+// STAGE: psi is narrower than 8 B per edge, so rank / ord overlay the sort arrays and every thread first pulls
+// its positions into registers; otherwise they lie beyond the sort arrays (4E + 2E + 2E bytes) and are written
+// directly.
 template <int NT, bool WANT_KEYS, bool STAGE>
-__device__ void unpack_sorted(const u64* S, int E, int Ev, u16* rank, u16* ord, u32* skey)
+__device__ void unpack_sorted(const u16* sorted, const u32* key32, int E, int Ev, u16* rank, u16* ord, u32* skey)
 {
     const int tid = threadIdx.x;
-    constexpr int MAXPT = STAGE ? (TDA_MAX_POINTS * (TDA_MAX_POINTS - 1) / 2 + NT - 1) / NT : 1;
-    u64 held[MAXPT];
     if (STAGE) {
+        constexpr int MAXPT = STAGE ? (TDA_MAX_POINTS * (TDA_MAX_POINTS - 1) / 2 + NT - 1) / NT : 1;
+        u32 held[MAXPT], hkey[WANT_KEYS ? MAXPT : 1];
 #pragma unroll
-        for (int k = 0; k < MAXPT; ++k) { const int e = tid + k * NT; held[k] = e < E ? S[e] : ~0ull; }
+        for (int k = 0; k < MAXPT; ++k) {
+            const int e = tid + k * NT;
+            held[k] = e < E ? (u32)sorted[e] : 0u;
+            if (WANT_KEYS) hkey[k] = e < E ? key32[edge_flat(held[k])] : 0u;
+        }
         __syncthreads();
 #pragma unroll
         for (int k = 0; k < MAXPT; ++k) {
             const int e = tid + k * NT;
             if (e < E) {
-                const u32 pk = (u32)(held[k] & 0xffffu);
-                const int a = (int)(pk >> 8), b = (int)(pk & 255u);
-                rank[tri2(a) + b] = (e < Ev) ? (u16)e : (u16)RANK_NONE;
-                ord[e] = (u16)pk;
+                rank[edge_flat(held[k])] = (e < Ev) ? (u16)e : (u16)RANK_NONE;
+                ord[e] = (u16)held[k];
+                if (WANT_KEYS) skey[e] = hkey[k];
             }
         }
     } else {
         for (int e = tid; e < E; e += NT) {
-            const u64 c = S[e];
-            const u32 pk = (u32)(c & 0xffffu);
-            const int a = (int)(pk >> 8), b = (int)(pk & 255u);
-            if (WANT_KEYS) skey[e] = (u32)(c >> 16);
-            rank[tri2(a) + b] = (e < Ev) ? (u16)e : (u16)RANK_NONE;
+            const u32 pk = sorted[e];
+            const int fl = edge_flat(pk);
+            if (WANT_KEYS) skey[e] = key32[fl];
+            rank[fl] = (e < Ev) ? (u16)e : (u16)RANK_NONE;
             ord[e] = (u16)pk;
         }
     }
@@ -975,15 +1019,17 @@ __device__ void rips_dm_window(unsigned char* smem, const int win, const double*
 {
     const int tid = threadIdx.x;
     const int E = tri2(n);
-    int npad = 2 * NT;
-    while (npad < E) npad <<= 1;
-    u64* S = reinterpret_cast<u64*>(smem);
+    u32* key32 = reinterpret_cast<u32*>(smem);
+    u16* ia = reinterpret_cast<u16*>(smem + L.off_ia);
+    u16* ib = reinterpret_cast<u16*>(smem + L.off_ib);
     Psi<W, WT>* psi = reinterpret_cast<Psi<W, WT>*>(smem);
     u16* rank = reinterpret_cast<u16*>(smem + L.off_rank);
     u16* ord = reinterpret_cast<u16*>(smem + L.off_ord);
     u32* skey = reinterpret_cast<u32*>(smem + L.off_aux);
     unsigned char* misc = smem + L.off_misc;
     int* red = reinterpret_cast<int*>(misc + MISC_MIN);
+    u16* cnt = reinterpret_cast<u16*>(misc + MISC_SORTCNT);
+    int* wsum = reinterpret_cast<int*>(misc + MISC_WV);
 
     PROF_BEGIN();
     const double* D = dm + (size_t)win * n * n;
@@ -1002,17 +1048,17 @@ __device__ void rips_dm_window(unsigned char* smem, const int win, const double*
             v = D[(size_t)b * n + a];
         }
         const u32 sk = f32_sortable((float)v);
-        S[e] = ((u64)sk << 16) | (u64)((a << 8) | b);
+        key32[e] = sk;
+        ia[e] = (u16)((a << 8) | b);
         atomicMax(&vmax[a], sk);
         atomicMax(&vmax[b], sk);
     }
-    for (int e = E + tid; e < npad; e += NT) S[e] = ~0ull;
     __syncthreads();
-    const int Ev = count_effective_edges<NT>(S, E, n, tkey, vmax, red);
+    const int Ev = count_effective_edges<NT>(key32, E, n, tkey, vmax, red);
     PROF_MARK(0);
-    bitonic_sort_lds<NT>(S, npad);
+    const u16* sorted = radix_sort_lds<NT>(key32, ia, ib, cnt, wsum, E);
     PROF_MARK(1);
-    unpack_sorted<NT, true, false>(S, E, Ev, rank, ord, skey);
+    unpack_sorted<NT, true, false>(sorted, key32, E, Ev, rank, ord, skey);
     PROF_MARK(2);
     int k0, k1, st;
     KeyFromLds kf{skey};
@@ -1076,7 +1122,9 @@ __device__ void rips_cloud_window(unsigned char* smem, const int win, const doub
                                   int* __restrict__ n_points, const RipsOut& out)
 {
     const int tid = threadIdx.x;
-    u64* S = reinterpret_cast<u64*>(smem);
+    u32* key32 = reinterpret_cast<u32*>(smem);
+    u16* ia = reinterpret_cast<u16*>(smem + L.off_ia);
+    u16* ib = reinterpret_cast<u16*>(smem + L.off_ib);
     Psi<W, WT>* psi = reinterpret_cast<Psi<W, WT>*>(smem);
     u16* rank = reinterpret_cast<u16*>(smem + L.off_rank);
     u16* ord = reinterpret_cast<u16*>(smem + L.off_ord);
@@ -1145,27 +1193,27 @@ __device__ void rips_cloud_window(unsigned char* smem, const int win, const doub
     }
     // P0. keys
     const int E = tri2(P);
-    int npad = 2 * NT;
-    while (npad < E) npad <<= 1;
     const u32 tkey = f32_sortable(thresh);
     KeyFromPts kf{pts, dim};
     u32* vmax = reinterpret_cast<u32*>(misc + MISC_COMP);
+    u16* cnt = reinterpret_cast<u16*>(misc + MISC_SORTCNT);
+    int* wsum = reinterpret_cast<int*>(misc + MISC_WV);
     if (tid < 128) vmax[tid] = 0u;
     __syncthreads();
     for (int e = tid; e < E; e += NT) {
         const int a = edge_row(e), b = e - tri2(a);
         const u32 sk = f32_sortable(kf(0, a, b));
-        S[e] = ((u64)sk << 16) | (u64)((a << 8) | b);
+        key32[e] = sk;
+        ia[e] = (u16)((a << 8) | b);
         atomicMax(&vmax[a], sk);
         atomicMax(&vmax[b], sk);
     }
-    for (int e = E + tid; e < npad; e += NT) S[e] = ~0ull;
     __syncthreads();
-    const int Ev = count_effective_edges<NT>(S, E, P, tkey, vmax, red);
+    const int Ev = count_effective_edges<NT>(key32, E, P, tkey, vmax, red);
     PROF_MARK(0);
-    bitonic_sort_lds<NT>(S, npad);
+    const u16* sorted = radix_sort_lds<NT>(key32, ia, ib, cnt, wsum, E);
     PROF_MARK(1);
-    unpack_sorted<NT, false, (sizeof(WT) < 8)>(S, E, Ev, rank, ord, nullptr);
+    unpack_sorted<NT, false, (sizeof(WT) * W < 8)>(sorted, key32, E, Ev, rank, ord, nullptr);
     PROF_MARK(2);
     int k0, k1, st;
     if (P <= 64)
@@ -1252,18 +1300,22 @@ static RipsLayout make_layout(int n, int psi_bytes_per_edge, int aux_bytes, int 
 {
     RipsLayout L;
     const int E = n * (n - 1) / 2;
-    int npad = 2 * NT;
-    while (npad < E) npad <<= 1;
     const int psi_bytes = E * psi_bytes_per_edge;
-    // the sort array may run past psi into rank / ord (written only after the sort); it must
-    // stop before aux (point cloud: read after the sort) and misc
+    // sort phase:  [key32 4E][edges 2E][edges 2E]      sweep phase:  [psi][rank 2E][ord 2E]
+    // both start at 0 (unpack_sorted stages through registers); aux (point cloud / sorted keys) and misc follow.
+    // The digit table of the sort (16 * NT u16) lies over the part of misc that only the sweep uses.
+    L.off_ia = 4 * E;                                  // packed: the sort arrays end at 8E exactly, so that they stay
+    L.off_ib = 6 * E;                                  // below rank / ord whenever psi has >= 8 bytes per edge
+    const int sort_end = align16(8 * E);
     L.off_rank = align16(psi_bytes);
     L.off_ord = align16(L.off_rank + 2 * E);
     int after_rank = align16(L.off_ord + 2 * E);
-    if (after_rank < npad * 8) after_rank = align16(npad * 8);
+    if (after_rank < sort_end) after_rank = sort_end;
     L.off_aux = after_rank;
     L.off_misc = align16(L.off_aux + aux_bytes);
-    L.total = align16(L.off_misc + MISC_BYTES(8 * psi_bytes_per_edge));
+    int misc_bytes = MISC_BYTES(8 * psi_bytes_per_edge);
+    if (misc_bytes < MISC_SORTCNT + 32 * NT) misc_bytes = MISC_SORTCNT + 32 * NT;
+    L.total = align16(L.off_misc + misc_bytes);
     return L;
 }
 
