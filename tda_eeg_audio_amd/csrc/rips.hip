@@ -190,6 +190,7 @@ __device__ u16* radix_sort_lds(const u32* key32, u16* ia, u16* ib, u16* cnt, int
         u64 c0 = 0ull, c1 = 0ull;                     // digits 0..7 / 8..15, 8 bits each
         const int dfirst = (int)((key32[edge_flat(cur[0])] >> shift) & 15u);
         bool same = true;
+#pragma unroll 4
         for (int p = p0; p < p1; ++p) {
             const int d = (int)((key32[edge_flat(cur[p])] >> shift) & 15u);
             same = same && d == dfirst;
@@ -213,13 +214,16 @@ __device__ u16* radix_sort_lds(const u32* key32, u16* ia, u16* ib, u16* cnt, int
         __syncthreads();
         // ---- scatter ----
         c0 = 0ull; c1 = 0ull;
+        const u16* __restrict__ src = cur;
+        u16* __restrict__ dstp = nxt;
+#pragma unroll 4
         for (int p = p0; p < p1; ++p) {
-            const u32 pk = cur[p];
+            const u32 pk = src[p];
             const int d = (int)((key32[edge_flat(pk)] >> shift) & 15u);
             const int sh = 8 * (d & 7);
             const int seen = (int)(((d < 8 ? c0 : c1) >> sh) & 255ull);
             if (d < 8) c0 += 1ull << sh; else c1 += 1ull << sh;
-            nxt[(int)cnt[d * NT + tid] + seen] = (u16)pk;
+            dstp[(int)cnt[d * NT + tid] + seen] = (u16)pk;
         }
         __syncthreads();
         u16* t_ = cur; cur = nxt; nxt = t_;
