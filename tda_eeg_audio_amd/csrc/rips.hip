@@ -10,9 +10,10 @@
 // ripser's (heap columns do not map to a GPU); it is an edge-parallel formulation of the same
 // persistence pairing:
 //
-//  P0  all n(n-1)/2 float32 edge lengths are packed as (sortable key << 16 | a << 8 | b); edges
-//      longer than min(thresh, enclosing radius) are dropped (they cannot contribute a row);
-//  P1  bitonic sort in LDS (whole workgroup, two butterfly stages per pass);
+//  P0  all n(n-1)/2 float32 edge lengths as sortable 32-bit keys; edges longer than
+//      min(thresh, enclosing radius) are dropped (they cannot contribute a row);
+//  P1  stable LSD radix sort in LDS (whole workgroup, four key bits per pass, the keys stay in place and
+//      the 16-bit edges (a << 8 | b) move): the order of (key, a, b);
 //  P2  rank[(a,b)] = r for the r-th edge (triangular u16 table, 0x7fff for edges beyond the effective
 //      threshold) and ord[r] = (a,b);
 //  P3  sweep over the filtration in chunks of NT consecutive edges, ONE EDGE PER LANE:
@@ -42,7 +43,7 @@
 //  P4  rows are written as float64 (float32-exact) pairs: H0 ascending death then the essential
 //      rows; H1 rows are ordered by a second tiny kernel (descending birth).
 //
-// LDS per workgroup: 30 KB (n = 47, 64 classes), 36 KB (128 classes) .. 77.5 KB (n = 124 point cloud, 32-bit classes).
+// LDS per workgroup: 26 KB (n = 47, 64 classes), 32 KB (128 classes) .. 79.2 KB (n = 124 point cloud, 32-bit classes).
 // Class capacity ladder: a first pass, then widening passes that redo only flagged windows (tda_set_retry_policy).
 // No MFMA: this is irregular integer work; the roofline that binds it is LDS latency/issue.
 #include "common.h"
