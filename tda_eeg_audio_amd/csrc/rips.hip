@@ -54,7 +54,7 @@
 
 // ---- optional phase profiling (make PROFILE=1): cycle sums per phase over all windows ----
 #ifdef TDA_PROFILE
-__device__ unsigned long long g_prof[24];
+__device__ unsigned long long g_prof[32];
 #define PROF_BEGIN() unsigned long long prof_t0 = clock64()
 #define PROF_MARK(i)                                                       \
     do {                                                                   \
@@ -65,9 +65,9 @@ __device__ unsigned long long g_prof[24];
 #define PROF_COUNT(i, v) do { if (threadIdx.x == 0) atomicAdd(&g_prof[i], (unsigned long long)(v)); } while (0)
 extern "C" __attribute__((visibility("default"))) int tda_profile_read(unsigned long long* out, int reset)
 {
-    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_prof), sizeof(unsigned long long) * 24) != hipSuccess) return 1;
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_prof), sizeof(unsigned long long) * 32) != hipSuccess) return 1;
     if (reset) {
-        unsigned long long z[24] = {0};
+        unsigned long long z[32] = {0};
         if (hipMemcpyToSymbol(HIP_SYMBOL(g_prof), z, sizeof(z)) != hipSuccess) return 1;
     }
     return 0;
@@ -547,6 +547,16 @@ __device__ void rips_sweep(int n, int E, int Ev, const u16* rank, const u16* ord
         }
         if (status) break;
         PROF_MARK(5);
+        // No class alive and none born in this chunk: every psi entry is zero (dead classes were substituted out,
+        // unwritten entries start at zero), so the apparent edges of the chunk get the zero vector they already hold
+        // and no triangle can kill anything.  Phases c and d are skipped; only the adjacency rows move on.  This is
+        // the state of the long-edge tail of a filtration.
+        bool quiet = btot == 0;
+#pragma unroll
+        for (int c = 0; c < W; ++c) quiet = quiet && alive[c] == 0;
+        u32* lcnt = reinterpret_cast<u32*>(misc + MISC_MIN);         // list header: [0] entries, [1] earliest key
+        if (quiet) PROF_COUNT(24, 1);
+        if (!quiet) {
         // ---- c. apparent edges: psi[e] = psi[a,v*] ^ psi[b,v*] ----
         // apex of the triangle that kills the edge at once: ANY common neighbour is valid (the other
         // triangles are verified below); prefer one whose two edges predate the chunk, so that
@@ -667,7 +677,6 @@ __device__ void rips_sweep(int n, int E, int Ev, const u16* rank, const u16* ord
         // class-indexed image table (one Psi per class) when it fits the list area; else kill records
         constexpr bool FTAB = WB * W * (int)sizeof(Psi<W, WT>) <= MISC_LIST_BYTES;
         constexpr int KMAX = FTAB ? 64 : LCAP;                       // kills per reduction round
-        u32* lcnt = reinterpret_cast<u32*>(misc + MISC_MIN);         // [0] entries, [1] earliest key
         unsigned char* list = misc + MISC_LIST;
         const u32 mws[4] = {m0, m1, m2, m3};
         int list_rounds = 0;
@@ -938,6 +947,7 @@ __device__ void rips_sweep(int n, int E, int Ev, const u16* rank, const u16* ord
             if (++list_rounds > 4 * NT) { status |= TDA_WIN_CLASS_OVERFLOW; break; }   // every round kills >= 1 class: never reached
             __syncthreads();            // table rewritten before the chunk is listed again
         }
+        }   // !quiet
         // the chunk's edges join the adjacency rows; the rows of the chunk's own edges (last read in phase a)
         // and the list header are reset for the next chunk under the same barrier
         if (valid && tid < clen) {
