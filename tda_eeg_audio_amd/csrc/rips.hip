@@ -957,6 +957,20 @@ __device__ void rips_sweep(int n, int E, int Ev, const u16* rank, const u16* ord
         if (tid < 256) adjc[tid] = 0ull;
         if (tid == 0) { lcnt[0] = 0u; lcnt[1] = 0xffffffffu; }
         __syncthreads();
+        // The end of the story: no class is alive and EVERY remaining edge already has a common neighbour, now and
+        // (adjacency only grows) at its own time.  Then no remaining edge is a candidate: no component can merge,
+        // no class can be born, and with nothing alive nothing can die -- the rest of the filtration adds no row.
+        if (quiet) {
+            bool covered = true;
+            for (int rr = r0 + clen + tid; rr < Ev && covered; rr += NT) {
+                const u32 pk = ord[rr];
+                const int ea = (int)(pk >> 8), eb = (int)(pk & 255u);
+                u64 common = adj[2 * ea] & adj[2 * eb];
+                if (NVW == 2) common |= adj[2 * ea + 1] & adj[2 * eb + 1];
+                covered = common != 0ull;
+            }
+            if (__syncthreads_and(covered ? 1 : 0)) { PROF_COUNT(25, 1); PROF_MARK(7); break; }
+        }
         PROF_MARK(7);
     }
     // essential classes
