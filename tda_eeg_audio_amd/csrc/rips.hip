@@ -54,15 +54,27 @@
 
 // ---- optional phase profiling (make PROFILE=1): cycle sums per phase over all windows ----
 #ifdef TDA_PROFILE
+// Per-workgroup sums live in LDS (thread 0 adds, no atomics) and are flushed to the global table once per
+// window: hundreds of workgroups hammering the same global counters at every mark cost more than the phases.
 __device__ unsigned long long g_prof[32];
-#define PROF_BEGIN() unsigned long long prof_t0 = clock64()
+__shared__ unsigned long long prof_lds[32];
+#define PROF_BEGIN()                                                       \
+    if (threadIdx.x < 32) prof_lds[threadIdx.x] = 0ull;                    \
+    __syncthreads();                                                       \
+    unsigned long long prof_t0 = clock64()
+#define PROF_RESUME() unsigned long long prof_t0 = clock64()
 #define PROF_MARK(i)                                                       \
     do {                                                                   \
         unsigned long long prof_t1 = clock64();                            \
-        if (threadIdx.x == 0) atomicAdd(&g_prof[i], prof_t1 - prof_t0);    \
+        if (threadIdx.x == 0) prof_lds[i] += prof_t1 - prof_t0;            \
         prof_t0 = prof_t1;                                                 \
     } while (0)
-#define PROF_COUNT(i, v) do { if (threadIdx.x == 0) atomicAdd(&g_prof[i], (unsigned long long)(v)); } while (0)
+#define PROF_COUNT(i, v) do { if (threadIdx.x == 0) prof_lds[i] += (unsigned long long)(v); } while (0)
+#define PROF_FLUSH()                                                       \
+    do {                                                                   \
+        __syncthreads();                                                   \
+        if (threadIdx.x < 32 && prof_lds[threadIdx.x]) atomicAdd(&g_prof[threadIdx.x], prof_lds[threadIdx.x]); \
+    } while (0)
 extern "C" __attribute__((visibility("default"))) int tda_profile_read(unsigned long long* out, int reset)
 {
     if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_prof), sizeof(unsigned long long) * 32) != hipSuccess) return 1;
@@ -74,8 +86,10 @@ extern "C" __attribute__((visibility("default"))) int tda_profile_read(unsigned 
 }
 #else
 #define PROF_BEGIN() do {} while (0)
+#define PROF_RESUME() do {} while (0)
 #define PROF_MARK(i) do {} while (0)
 #define PROF_COUNT(i, v) do {} while (0)
+#define PROF_FLUSH() do {} while (0)
 #endif
 
 #define WAVE_SYNC()                                            \
@@ -357,7 +371,7 @@ __device__ void rips_sweep(int n, int E, int Ev, const u16* rank, const u16* ord
     int compA = lane, compB = lane + 64;     // component labels of vertices lane / lane+64 (used by wave 0)
 
     int clen = NT;
-    PROF_BEGIN();
+    PROF_RESUME();
     for (int r0 = 0; r0 < Ev && !status; r0 += clen) {
         clen = NT;
         PROF_MARK(15);
@@ -1097,6 +1111,7 @@ __device__ void rips_dm_window(unsigned char* smem, const int win, const double*
     PROF_MARK(3);
     PROF_COUNT(8, 1);
     PROF_COUNT(9, E);
+    PROF_FLUSH();
     if (tid == 0) { out.h0_cnt[win] = k0; out.h1_cnt[win] = k1; out.status[win] = st; }
 }
 
@@ -1252,6 +1267,7 @@ __device__ void rips_cloud_window(unsigned char* smem, const int win, const doub
     PROF_MARK(3);
     PROF_COUNT(8, 1);
     PROF_COUNT(9, E);
+    PROF_FLUSH();
     if (tid == 0) { out.h0_cnt[win] = k0; out.h1_cnt[win] = k1; out.status[win] = st; }
 }
 
