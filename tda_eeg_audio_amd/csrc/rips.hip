@@ -439,13 +439,78 @@ __device__ void rips_sweep(int n, int E, int Ev, const u16* rank, const u16* ord
         int nfree = 0;
 #pragma unroll
         for (int c = 0; c < W; ++c) nfree += __builtin_popcountll((u64)(WT)~alive[c]);
+        // Many candidates (the first chunks, where the forest grows): Boruvka rounds by the whole workgroup instead
+        // of the sequential walk.  Every component picks its earliest incident candidate (cut property: with
+        // distinct ranks it is a forest edge, i.e. a merge of Kruskal's order); the picked edges are contracted by
+        // pointer jumping; candidates whose ends meet in one component without having been picked are births.
+        // O(log n) rounds whatever the order of the edges.  The labels travel through LDS for the occasion.
+        int ncand = 0;
+#pragma unroll
+        for (int w = 0; w < NT / 64; ++w) ncand += __builtin_popcountll(cand[w]);
+        const bool par = ncand > 24;
+        const int lblA0 = compA, lblB0 = compB;                  // labels at chunk start (wave 0)
+        if (par) {
+            int* bcomp = reinterpret_cast<int*>(misc + MISC_LIST + 1024);    // [128] label of every vertex
+            u32* bbest = reinterpret_cast<u32*>(bcomp + 128);                // [128] earliest candidate at a label
+            int* bpar = reinterpret_cast<int*>(bcomp + 256);                 // [128] contraction pointers
+            if (wave == 0) { bcomp[lane] = compA; bcomp[64 + lane] = compB; }
+            if (tid < 128) bbest[tid] = 0xffffffffu;
+            __syncthreads();
+            bool live = is_cand, picked = false;
+            for (int round = 0; round < 64; ++round) {
+                int ca = 0, cb2 = 0;
+                if (live) {
+                    ca = bcomp[a]; cb2 = bcomp[b];
+                    if (ca == cb2) live = false;                          // ends already joined: a birth
+                    else { atomicMin(&bbest[ca], (u32)tid); atomicMin(&bbest[cb2], (u32)tid); }
+                }
+                if (!__syncthreads_or(live ? 1 : 0)) break;
+                // every label with a best edge points at the label on the other side of it
+                if (tid < 128) {
+                    int pp = tid;
+                    const u32 bp = bbest[tid];
+                    if (bp != 0xffffffffu) {
+                        const u32 pk = ord[r0 + (int)bp];
+                        const int oa = bcomp[pk >> 8], ob = bcomp[pk & 255u];
+                        pp = oa == tid ? ob : oa;
+                    }
+                    bpar[tid] = pp;
+                }
+                __syncthreads();
+                // two labels that picked the same edge point at each other: the smaller one becomes the root
+                if (tid < 128) { const int pp = bpar[tid]; if (pp != tid && bpar[pp] == tid && tid < pp) bpar[tid] = tid; }
+                __syncthreads();
+                for (int it = 0; it < 8; ++it) {                           // pointer jumping (any mix of old and new
+                    bool moved = false;                                    // values still points at an ancestor)
+                    if (tid < 128) { const int pp = bpar[tid], gp = bpar[pp]; if (gp != pp) { bpar[tid] = gp; moved = true; } }
+                    if (!__syncthreads_or(moved ? 1 : 0)) break;
+                }
+                if (live && (bbest[ca] == (u32)tid || bbest[cb2] == (u32)tid)) { picked = true; live = false; }
+                __syncthreads();                                           // all reads of bbest / bcomp of this round done
+                if (tid < 128) { bcomp[tid] = bpar[bcomp[tid]]; bbest[tid] = 0xffffffffu; }
+                __syncthreads();
+            }
+            {
+                const u64 mb = __ballot(picked);
+                if (lane == 0) mbal[wave] = mb;
+            }
+            __syncthreads();
+            if (wave == 0) { compA = bcomp[lane]; compB = bcomp[64 + lane]; }
+        }
         if (wave == 0) {
             // The walk stops at the first birth that finds no free class bit: the chunk is closed just before
             // that edge, so that the kills of the shortened chunk can free bits (capacity = classes alive at
             // once).  q = NT: the whole chunk went through.
             const u64 candv = cand[lane & (NT / 64 - 1)];     // all ballots in one LDS read
             int q = NT, births = 0;
-            for (int g = 0; g < NT / 64; ++g) {
+            bool walk = !par;
+            if (par) {                                        // the rounds classified everything: do the births fit?
+                int nbirth = 0;
+#pragma unroll
+                for (int w = 0; w < NT / 64; ++w) nbirth += __builtin_popcountll(cand[w] & ~mbal[w]);
+                if (nbirth > nfree) { walk = true; compA = lblA0; compB = lblB0; }      // rare: sequential, with the cut
+            }
+            for (int g = 0; g < NT / 64 && walk; ++g) {
                 u64 cb = q == NT ? rl64(candv, g) : 0ull;
                 u64 mm = 0ull;
                 if (cb) {
