@@ -38,6 +38,9 @@
 //         exactly once per H1 class that ever dies (tens per window).  All non-trivial triangles of a
 //         chunk are listed at once; wave 0 reduces the list in registers (the substitutions are
 //         linear maps) and the psi table is rewritten once per chunk through a class -> image table.
+//      Chunks in which no class is alive and none is born skip c and d (every psi entry is zero); once, in that
+//      state, every remaining edge already has a common neighbour, nothing can happen any more and the sweep
+//      stops.  Candidate-rich chunks decide b by Boruvka rounds of the whole workgroup.
 //      The multiset of (birth,death) pairs equals that of any persistence algorithm on the
 //      same filtration; tie order inside equal diameters does not change it.
 //  P4  rows are written as float64 (float32-exact) pairs: H0 ascending death then the essential
