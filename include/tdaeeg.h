@@ -284,7 +284,7 @@ tda_status tda_event_record(tda_ctx* ctx, void* ev, void* stream);
 tda_status tda_event_elapsed_ms(tda_ctx* ctx, void* ev_start, void* ev_stop, float* ms); /* syncs on stop */
 tda_status tda_event_destroy(tda_ctx* ctx, void* ev);
 tda_status tda_stream_sync(tda_ctx* ctx, void* stream);
-/* Arms a one-shot probe: the NEXT launch of the first-pass kernel of `which` made through this
+/* Arms a one-shot probe (one slot per `which`; TDA_PROBE_NONE clears all): the NEXT launch of the first-pass kernel of `which` made through this
  * context records ev_start right before and ev_stop right after that ONE kernel on its stream
  * (the retry passes and the row-ordering kernel of the same call are outside the bracket).  This is
  * the per-kernel duration bench.py's roofline uses; rocprofv3 --kernel-trace reports the same kernel.

@@ -623,10 +623,14 @@ tda_status tda_set_kernel_probe(tda_ctx* ctx, int which, void* ev_start, void* e
     if (which != TDA_PROBE_NONE && !(ev_start && ev_stop) && !dev_span)
         TDA_FAIL(ctx, TDA_ERR_INVALID, "probe needs two events or a span buffer");
     if ((ev_start == nullptr) != (ev_stop == nullptr)) TDA_FAIL(ctx, TDA_ERR_INVALID, "probe events come in pairs");
-    ctx->probe_which = which;
-    ctx->probe_start = (hipEvent_t)ev_start;
-    ctx->probe_stop = (hipEvent_t)ev_stop;
-    ctx->probe_span = (unsigned long long*)dev_span;
+    if (which == TDA_PROBE_NONE) {
+        for (int w = 0; w < 4; ++w) ctx->probe[w] = tda_ctx::Probe();
+        return TDA_OK;
+    }
+    ctx->probe[which].start = (hipEvent_t)ev_start;
+    ctx->probe[which].stop = (hipEvent_t)ev_stop;
+    ctx->probe[which].span = (unsigned long long*)dev_span;
+    ctx->probe[which].armed = true;
     return TDA_OK;
 }
 tda_status tda_stream_sync(tda_ctx* ctx, void* stream)

@@ -18,26 +18,27 @@ struct tda_ctx {
     void* ws = nullptr;
     size_t ws_bytes = 0;
     std::string err;
-    // one-shot kernel probe (tda_set_kernel_probe)
-    int probe_which = 0;
-    hipEvent_t probe_start = nullptr, probe_stop = nullptr;
-    unsigned long long* probe_span = nullptr;   // device u64[4] {~0, 0, 0, 0}: see rips_cloud_kernel
+    // one-shot kernel probes (tda_set_kernel_probe), one slot per probed kernel
+    struct Probe { hipEvent_t start = nullptr, stop = nullptr; unsigned long long* span = nullptr; bool armed = false; };
+    Probe probe[4];
 };
 
-// brackets ONE kernel launch with the armed probe events (if `which` is armed)
+// brackets ONE kernel launch with the armed probe of `which` (if any) and disarms it
 struct ProbeScope {
-    tda_ctx* ctx; hipStream_t st; bool on; unsigned long long* span;
-    ProbeScope(tda_ctx* c, int which, hipStream_t s)
-        : ctx(c), st(s), on(c->probe_which == which && ((c->probe_start && c->probe_stop) || c->probe_span)),
-          span(c->probe_span)
+    tda_ctx* ctx; hipStream_t st; int which; bool on; unsigned long long* span;
+    ProbeScope(tda_ctx* c, int w, hipStream_t s)
+        : ctx(c), st(s), which(w), on(w > 0 && w < 4 && c->probe[w].armed), span(nullptr)
     {
-        if (on && ctx->probe_start) (void)hipEventRecord(ctx->probe_start, st);
+        if (on) {
+            span = ctx->probe[which].span;
+            if (ctx->probe[which].start) (void)hipEventRecord(ctx->probe[which].start, st);
+        }
     }
     ~ProbeScope()
     {
         if (on) {
-            if (ctx->probe_stop) (void)hipEventRecord(ctx->probe_stop, st);
-            ctx->probe_which = 0; ctx->probe_start = ctx->probe_stop = nullptr; ctx->probe_span = nullptr;
+            if (ctx->probe[which].stop) (void)hipEventRecord(ctx->probe[which].stop, st);
+            ctx->probe[which] = tda_ctx::Probe();
         }
     }
 };

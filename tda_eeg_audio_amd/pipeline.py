@@ -197,6 +197,8 @@ class Lanes:
         if self.graph and timers is None:
             g = self.graphs.get(key)
             if g is None:
+                if self.before_step is not None:
+                    self.before_step(i)
                 with torch.cuda.stream(st):                  # eager once: lazy initialisations stay out of the capture
                     run_step(eeg_win, audio_win, ws, ctx=ctx, max_lag=max_lag, retry=retry)
                 st.synchronize()
