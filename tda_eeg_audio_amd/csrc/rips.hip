@@ -452,52 +452,73 @@ __device__ void rips_sweep(int n, int E, int Ev, const u16* rank, const u16* ord
         for (int w = 0; w < NT / 64; ++w) ncand += __builtin_popcountll(cand[w]);
         const bool par = ncand > 24;
         const int lblA0 = compA, lblB0 = compB;                  // labels at chunk start (wave 0)
+        int qpar = NT;                                           // cut of the chunk found by the parallel path
         if (par) {
             int* bcomp = reinterpret_cast<int*>(misc + MISC_LIST + 1024);    // [128] label of every vertex
             u32* bbest = reinterpret_cast<u32*>(bcomp + 128);                // [128] earliest candidate at a label
             int* bpar = reinterpret_cast<int*>(bcomp + 256);                 // [128] contraction pointers
-            if (wave == 0) { bcomp[lane] = compA; bcomp[64 + lane] = compB; }
-            if (tid < 128) bbest[tid] = 0xffffffffu;
-            __syncthreads();
-            bool live = is_cand, picked = false;
-            for (int round = 0; round < 64; ++round) {
-                int ca = 0, cb2 = 0;
-                if (live) {
-                    ca = bcomp[a]; cb2 = bcomp[b];
-                    if (ca == cb2) live = false;                          // ends already joined: a birth
-                    else { atomicMin(&bbest[ca], (u32)tid); atomicMin(&bbest[cb2], (u32)tid); }
-                }
-                if (!__syncthreads_or(live ? 1 : 0)) break;
-                // every label with a best edge points at the label on the other side of it
-                if (tid < 128) {
-                    int pp = tid;
-                    const u32 bp = bbest[tid];
-                    if (bp != 0xffffffffu) {
-                        const u32 pk = ord[r0 + (int)bp];
-                        const int oa = bcomp[pk >> 8], ob = bcomp[pk & 255u];
-                        pp = oa == tid ? ob : oa;
+            // classify the candidates at chunk positions < limit, starting from the labels of the chunk start
+            auto rounds = [&](int limit) {
+                if (wave == 0) { bcomp[lane] = lblA0; bcomp[64 + lane] = lblB0; }
+                if (tid < 128) bbest[tid] = 0xffffffffu;
+                __syncthreads();
+                bool live = is_cand && tid < limit, picked = false;
+                for (int round = 0; round < 64; ++round) {
+                    int ca = 0, cb2 = 0;
+                    if (live) {
+                        ca = bcomp[a]; cb2 = bcomp[b];
+                        if (ca == cb2) live = false;                          // ends already joined: a birth
+                        else { atomicMin(&bbest[ca], (u32)tid); atomicMin(&bbest[cb2], (u32)tid); }
                     }
-                    bpar[tid] = pp;
+                    if (!__syncthreads_or(live ? 1 : 0)) break;
+                    if (live && (bbest[ca] == (u32)tid || bbest[cb2] == (u32)tid)) { picked = true; live = false; }
+                    // every label with a best edge points at the label on the other side of it
+                    if (tid < 128) {
+                        int pp = tid;
+                        const u32 bp = bbest[tid];
+                        if (bp != 0xffffffffu) {
+                            const u32 pk = ord[r0 + (int)bp];
+                            const int oa = bcomp[pk >> 8], ob = bcomp[pk & 255u];
+                            pp = oa == tid ? ob : oa;
+                        }
+                        bpar[tid] = pp;
+                    }
+                    __syncthreads();
+                    // two labels that picked the same edge point at each other: the smaller one becomes the root
+                    if (tid < 128) { const int pp = bpar[tid]; if (pp != tid && bpar[pp] == tid && tid < pp) bpar[tid] = tid; }
+                    __syncthreads();
+                    for (int it = 0; it < 8; ++it) {                           // pointer jumping (any mix of old and new
+                        bool moved = false;                                    // values still points at an ancestor)
+                        if (tid < 128) { const int pp = bpar[tid], gp = bpar[pp]; if (gp != pp) { bpar[tid] = gp; moved = true; } }
+                        if (!__syncthreads_or(moved ? 1 : 0)) break;
+                    }
+                    // (the barriers of the pointer jumping separate this round's reads of bbest / bcomp from these writes)
+                    if (tid < 128) { bcomp[tid] = bpar[bcomp[tid]]; bbest[tid] = 0xffffffffu; }
+                    __syncthreads();
                 }
-                __syncthreads();
-                // two labels that picked the same edge point at each other: the smaller one becomes the root
-                if (tid < 128) { const int pp = bpar[tid]; if (pp != tid && bpar[pp] == tid && tid < pp) bpar[tid] = tid; }
-                __syncthreads();
-                for (int it = 0; it < 8; ++it) {                           // pointer jumping (any mix of old and new
-                    bool moved = false;                                    // values still points at an ancestor)
-                    if (tid < 128) { const int pp = bpar[tid], gp = bpar[pp]; if (gp != pp) { bpar[tid] = gp; moved = true; } }
-                    if (!__syncthreads_or(moved ? 1 : 0)) break;
-                }
-                if (live && (bbest[ca] == (u32)tid || bbest[cb2] == (u32)tid)) { picked = true; live = false; }
-                __syncthreads();                                           // all reads of bbest / bcomp of this round done
-                if (tid < 128) { bcomp[tid] = bpar[bcomp[tid]]; bbest[tid] = 0xffffffffu; }
-                __syncthreads();
-            }
-            {
                 const u64 mb = __ballot(picked);
                 if (lane == 0) mbal[wave] = mb;
+                __syncthreads();
+            };
+            rounds(NT);
+            // do the births fit the free class bits?  If not, the chunk ends just before the first birth that does
+            // not fit (Kruskal's decisions for the edges before it do not depend on the later ones): classify again
+            // up to there, so that the labels contain exactly the merges of the shortened chunk
+            int nbirth = 0, wcut = -1, before = 0;
+#pragma unroll
+            for (int w = 0; w < NT / 64; ++w) {
+                const int nb = __builtin_popcountll(cand[w] & ~mbal[w]);
+                if (wcut < 0 && nbirth + nb > nfree) { wcut = w; before = nbirth; }
+                nbirth += nb;
             }
-            __syncthreads();
+            if (wcut >= 0) {
+                u64 bw = cand[wcut] & ~mbal[wcut];
+                for (int k = before; k < nfree; ++k) bw &= bw - 1ull;          // drop the births that still fit
+                qpar = 64 * wcut + __builtin_ctzll(bw);
+                PROF_COUNT(26, 1);
+                __syncthreads();                                               // every thread has read the ballots
+                rounds(qpar);
+            }
             if (wave == 0) { compA = bcomp[lane]; compB = bcomp[64 + lane]; }
         }
         if (wave == 0) {
@@ -505,14 +526,8 @@ __device__ void rips_sweep(int n, int E, int Ev, const u16* rank, const u16* ord
             // that edge, so that the kills of the shortened chunk can free bits (capacity = classes alive at
             // once).  q = NT: the whole chunk went through.
             const u64 candv = cand[lane & (NT / 64 - 1)];     // all ballots in one LDS read
-            int q = NT, births = 0;
-            bool walk = !par;
-            if (par) {                                        // the rounds classified everything: do the births fit?
-                int nbirth = 0;
-#pragma unroll
-                for (int w = 0; w < NT / 64; ++w) nbirth += __builtin_popcountll(cand[w] & ~mbal[w]);
-                if (nbirth > nfree) { walk = true; compA = lblA0; compB = lblB0; }      // rare: sequential, with the cut
-            }
+            int q = par ? qpar : NT, births = 0;
+            const bool walk = !par;
             for (int g = 0; g < NT / 64 && walk; ++g) {
                 u64 cb = q == NT ? rl64(candv, g) : 0ull;
                 u64 mm = 0ull;
