@@ -450,6 +450,8 @@ __device__ void rips_sweep(int n, int E, int Ev, const u16* rank, const u16* ord
         int ncand = 0;
 #pragma unroll
         for (int w = 0; w < NT / 64; ++w) ncand += __builtin_popcountll(cand[w]);
+        int btot = 0;                                            // births of this chunk
+        if (ncand > 0) {                                         // (a chunk without candidates has no phase b at all)
         const bool par = ncand > 24;
         const int lblA0 = compA, lblB0 = compB;                  // labels at chunk start (wave 0)
         int qpar = NT;                                           // cut of the chunk found by the parallel path
@@ -606,7 +608,8 @@ __device__ void rips_sweep(int n, int E, int Ev, const u16* rank, const u16* ord
         const u64 below = (1ull << lane) - 1ull;
         const int bpre = offs[wave] + __builtin_popcountll(__ballot(birth) & below);
         const int rpre = offs[8 + wave] + __builtin_popcountll(__ballot(row) & below);
-        const int btot = offs[16], rtot = offs[17], mtot = offs[18];
+        btot = offs[16];
+        const int rtot = offs[17], mtot = offs[18];
         if (!status) {
             if (row) {
                 const int pos = k0 + rpre;
@@ -642,6 +645,7 @@ __device__ void rips_sweep(int n, int E, int Ev, const u16* rank, const u16* ord
                 }
             }
         }
+        }   // ncand > 0
         if (status) break;
         PROF_MARK(5);
         // No class alive and none born in this chunk: every psi entry is zero (dead classes were substituted out,
