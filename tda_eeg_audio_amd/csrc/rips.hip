@@ -296,16 +296,17 @@ template <int NT>
 __device__ int count_effective_edges(const u32* key32, int E, int n, u32 tkey, const u32* vmax, int* red)
 {
     const int tid = threadIdx.x;
-    u32 renc = 0xffffffffu;
-    for (int v = 0; v < n; ++v) { const u32 m = vmax[v]; renc = m < renc ? m : renc; }
+    // enclosing radius: every wave takes the minimum over the (<= 128) vertices, two per lane, on the DPP network
+    const int lane = tid & 63;
+    const u32 m0 = lane < n ? vmax[lane] : 0xffffffffu, m1 = lane + 64 < n ? vmax[lane + 64] : 0xffffffffu;
+    const u32 renc = wave_min_u32_dpp(m0 < m1 ? m0 : m1);
     const u32 teff = renc < tkey ? renc : tkey;
     int ev = 0;
     for (int e = tid; e < E; e += NT) ev += (key32[e] <= teff) ? 1 : 0;
     if (tid == 0) *red = 0;
     __syncthreads();
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) ev += __shfl_xor(ev, off, 64);
-    if ((tid & 63) == 0) atomicAdd(red, ev);
+    ev = wave_incl_scan_i32(ev);                      // lane 63 holds the wave's sum
+    if (lane == 63) atomicAdd(red, ev);
     __syncthreads();
     return *red;
 }
@@ -1302,18 +1303,17 @@ __device__ void rips_cloud_window(unsigned char* smem, const int win, const doub
     }
     __syncthreads();
     if (normalise) {
-        if (tid < 64) {
-            for (int k = 0; k < dim; ++k) {
-                double mn = INFINITY, mx = -INFINITY;
-                for (int i = tid; i < P; i += 64) {
-                    const double v = pts[i * dim + k];
-                    mn = v < mn ? v : mn;
-                    mx = v > mx ? v : mx;
-                }
-                mn = wave_min_f64(mn);
-                mx = wave_max_f64(mx);
-                if (tid == 0) { double rg = mx - mn; if (rg == 0.0) rg = 1.0; mm[2 * k] = mn; mm[2 * k + 1] = rg; }
+        if ((tid >> 6) < dim) {                            // one wave per column (dim <= 4)
+            const int k = tid >> 6, l = tid & 63;
+            double mn = INFINITY, mx = -INFINITY;
+            for (int i = l; i < P; i += 64) {
+                const double v = pts[i * dim + k];
+                mn = v < mn ? v : mn;
+                mx = v > mx ? v : mx;
             }
+            mn = wave_min_f64(mn);
+            mx = wave_max_f64(mx);
+            if (l == 0) { double rg = mx - mn; if (rg == 0.0) rg = 1.0; mm[2 * k] = mn; mm[2 * k + 1] = rg; }
         }
         __syncthreads();
         for (int idx = tid; idx < P * dim; idx += NT) {
