@@ -395,17 +395,19 @@ __device__ void rips_sweep(int n, int E, int Ev, const u16* rank, const u16* ord
         u64 M[NVW], M0[NVW];     // M: common neighbours before edge r; M0: those already common at chunk start
 #pragma unroll
         for (int w = 0; w < NVW; ++w) { M[w] = 0; M0[w] = 0; }
-        if (valid) {
-            // Common neighbours at chunk start come from the adjacency bit rows.  A vertex can only have
-            // become common since then through an edge of this chunk: those few candidates (bit rows of
-            // the chunk's edges) are confirmed against the rank matrix -- both edges older than r.
+        // Common neighbours at chunk start come from the adjacency bit rows.  A vertex can only have become common
+        // since then through an edge of this chunk: those few candidates (bit rows of the chunk's edges) are
+        // confirmed against the rank table -- both edges older than r.  While no class is alive the exact mask only
+        // matters for edges that have no common neighbour yet (are they candidates?), so the confirmation of the
+        // others waits until a birth in this chunk makes it necessary (`lazy`).
+        bool lazy = true;
+#pragma unroll
+        for (int c = 0; c < W; ++c) lazy = lazy && alive[c] == 0;
+        auto confirm = [&]() {
             const int ta0 = tri2(a), tb0 = tri2(b);
 #pragma unroll
             for (int w = 0; w < NVW; ++w) {
-                const u64 A0 = adj[2 * a + w], B0 = adj[2 * b + w];
-                M0[w] = A0 & B0;
-                M[w] = M0[w];
-                u64 cc = (A0 | adjc[2 * a + w]) & (B0 | adjc[2 * b + w]) & ~M0[w];
+                u64 cc = (adj[2 * a + w] | adjc[2 * a + w]) & (adj[2 * b + w] | adjc[2 * b + w]) & ~M0[w];
                 while (cc) {
                     const int v0 = 64 * w + __builtin_ctzll(cc); cc &= cc - 1ull;
                     const bool ok1 = cc != 0ull; const int v1 = ok1 ? 64 * w + __builtin_ctzll(cc) : v0; cc &= cc - 1ull;
@@ -416,6 +418,14 @@ __device__ void rips_sweep(int n, int E, int Ev, const u16* rank, const u16* ord
                     if (ok1 && (int)(xa1 > xb1 ? xa1 : xb1) < r) M[w] |= 1ull << (v1 & 63);
                 }
             }
+        };
+        bool deferred = false;                       // this lane's confirmation is still owed
+        if (valid) {
+            u64 any0 = 0ull;
+#pragma unroll
+            for (int w = 0; w < NVW; ++w) { M0[w] = adj[2 * a + w] & adj[2 * b + w]; M[w] = M0[w]; any0 |= M0[w]; }
+            if (lazy && any0) deferred = true;
+            else confirm();
         }
         u64 many = 0;
 #pragma unroll
@@ -648,6 +658,7 @@ __device__ void rips_sweep(int n, int E, int Ev, const u16* rank, const u16* ord
         }
         }   // ncand > 0
         if (status) break;
+        if (deferred && btot > 0) confirm();         // a class was born after all: the chunk needs the exact masks
         PROF_MARK(5);
         // No class alive and none born in this chunk: every psi entry is zero (dead classes were substituted out,
         // unwritten entries start at zero), so the apparent edges of the chunk get the zero vector they already hold
