@@ -493,12 +493,11 @@ __device__ void rips_sweep(int n, int E, int Ev, const u16* rank, const u16* ord
                             const u32 pk = ord[r0 + (int)bp];
                             const int oa = bcomp[pk >> 8], ob = bcomp[pk & 255u];
                             pp = oa == tid ? ob : oa;
+                            // two labels that picked the same edge would point at each other: the smaller one is the root
+                            if (bbest[pp] == bp && tid < pp) pp = tid;
                         }
                         bpar[tid] = pp;
                     }
-                    __syncthreads();
-                    // two labels that picked the same edge point at each other: the smaller one becomes the root
-                    if (tid < 128) { const int pp = bpar[tid]; if (pp != tid && bpar[pp] == tid && tid < pp) bpar[tid] = tid; }
                     __syncthreads();
                     for (int it = 0; it < 8; ++it) {                           // pointer jumping (any mix of old and new
                         bool moved = false;                                    // values still points at an ancestor)
