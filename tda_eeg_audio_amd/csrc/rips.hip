@@ -375,6 +375,7 @@ __device__ void rips_sweep(int n, int E, int Ev, const u16* rank, const u16* ord
     int compA = lane, compB = lane + 64;     // component labels of vertices lane / lane+64 (used by wave 0)
 
     int clen = NT;
+    int cov_next = tid;                          // coverage check: first edge of this thread's residue class not yet seen covered
     PROF_RESUME();
     for (int r0 = 0; r0 < Ev && !status; r0 += clen) {
         clen = NT;
@@ -1073,14 +1074,21 @@ __device__ void rips_sweep(int n, int E, int Ev, const u16* rank, const u16* ord
         // (adjacency only grows) at its own time.  Then no remaining edge is a candidate: no component can merge,
         // no class can be born, and with nothing alive nothing can die -- the rest of the filtration adds no row.
         if (quiet) {
+            // every thread walks its own residue class of the remaining edges and remembers where it stopped: an edge
+            // that is covered stays covered, so no edge is looked at twice over all the checks of a window
+            const int from = r0 + clen;
+            int rr = from + ((tid - from) & (NT - 1));
+            rr = rr > cov_next ? rr : cov_next;
             bool covered = true;
-            for (int rr = r0 + clen + tid; rr < Ev && covered; rr += NT) {
+            while (rr < Ev) {
                 const u32 pk = ord[rr];
                 const int ea = (int)(pk >> 8), eb = (int)(pk & 255u);
                 u64 common = adj[2 * ea] & adj[2 * eb];
                 if (NVW == 2) common |= adj[2 * ea + 1] & adj[2 * eb + 1];
-                covered = common != 0ull;
+                if (common == 0ull) { covered = false; break; }
+                rr += NT;
             }
+            cov_next = rr;
             if (__syncthreads_and(covered ? 1 : 0)) { PROF_COUNT(25, 1); PROF_MARK(7); break; }
         }
         PROF_MARK(7);
