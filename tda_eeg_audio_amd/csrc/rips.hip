@@ -692,11 +692,15 @@ __device__ void rips_sweep(int n, int E, int Ev, const u16* rank, const u16* ord
             q1 = (int)rank[d1] - r0; q2 = (int)rank[d2] - r0;   // < tid
         }
         bool pending = apparent;
-        if (!apparent) done[tid] = 1;       // candidates (and idle lanes) are settled
-        __syncthreads();
         Psi<W, WT> base = pzero<W, WT>();
-        // rounds: a lane is ready when both dependencies are settled (almost always at once, see v*)
-        while (true) {
+        if (apparent && q1 < 0 && q2 < 0) {  // both edges predate the chunk (see v*): final already, no waiting
+            base = pxor(psi[d1], psi[d2]);
+            psi[tab] = base;
+            pending = false;
+        }
+        if (!pending) done[tid] = 1;        // candidates, idle lanes and the lanes above are settled
+        // rounds for the rest: a lane is ready when both dependencies are settled
+        while (__syncthreads_or(pending ? 1 : 0)) {
             bool ready = false;
             if (pending) ready = (q1 < 0 || done[q1]) && (q2 < 0 || done[q2]);
             __syncthreads();                 // all flag reads of this round precede its flag writes
@@ -706,7 +710,6 @@ __device__ void rips_sweep(int n, int E, int Ev, const u16* rank, const u16* ord
                 done[tid] = 1;
                 pending = false;
             }
-            if (__syncthreads_count(pending) == 0) break;
         }
         PROF_MARK(6);
         // ---- d. the other triangles of every apparent edge ----
