@@ -1007,8 +1007,11 @@ __device__ void rips_sweep(int n, int E, int Ev, const u16* rank, const u16* ord
             if (FTAB) {
                 // ---- rewrite: p -> (p minus killed classes) ^ images of the killed classes it contained ----
                 const Psi<W, WT>* ftab = reinterpret_cast<const Psi<W, WT>*>(list);
+                // only edges that have entered the filtration can carry class bits: walk them by rank
+                const int seen_end = r0 + clen;
 #pragma unroll 4
-                for (int e = tid; e < E; e += NT) {
+                for (int rr = tid; rr < seen_end; rr += NT) {
+                    const int e = edge_flat(ord[rr]);
                     const Psi<W, WT> p = psi[e];
                     WT anyh = 0;
 #pragma unroll
@@ -1041,7 +1044,8 @@ __device__ void rips_sweep(int n, int E, int Ev, const u16* rank, const u16* ord
                         for (int c = 0; c < W; ++c) kw[j].w[c] = *reinterpret_cast<const WT*>(list + ES * jj + 4 + c * (int)sizeof(WT));
                     }
 #pragma unroll 4
-                    for (int e = tid; e < E; e += NT) {
+                    for (int rr = tid; rr < r0 + clen; rr += NT) {
+                        const int e = edge_flat(ord[rr]);
                         Psi<W, WT> p = psi[e];
                         bool changed = false;
 #pragma unroll
