@@ -795,6 +795,14 @@ __device__ void rips_sweep(int n, int E, int Ev, const u16* rank, const u16* ord
         constexpr int KMAX = FTAB ? 64 : LCAP;                       // kills per reduction round
         unsigned char* list = misc + MISC_LIST;
         const u32 mws[4] = {m0, m1, m2, m3};
+#ifdef TDA_PROFILE
+        {   // diagnostic: triangles left to test after the link closure, and apparent edges
+            const int ntri = __builtin_popcount(m0) + __builtin_popcount(m1) + __builtin_popcount(m2) + __builtin_popcount(m3);
+            if (ntri) atomicAdd(&prof_lds[27], (unsigned long long)ntri);
+            if (apparent) atomicAdd(&prof_lds[28], 1ull);
+            if (ntri) atomicAdd(&prof_lds[29], 1ull);
+        }
+#endif
         int list_rounds = 0;
         while (true) {
             if (list_rounds > 0) {                     // the first listing finds the header reset (chunk end)
