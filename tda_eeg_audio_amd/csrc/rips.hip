@@ -1016,7 +1016,7 @@ __device__ void rips_sweep(int n, int E, int Ev, const u16* rank, const u16* ord
                 // ---- rewrite: p -> (p minus killed classes) ^ images of the killed classes it contained ----
                 const Psi<W, WT>* ftab = reinterpret_cast<const Psi<W, WT>*>(list);
                 // only edges that have entered the filtration can carry class bits: walk them by rank
-                const int seen_end = r0 + clen;
+                const int seen_end = r0 + clen < Ev ? r0 + clen : Ev;          // the last chunk may be short
 #pragma unroll 4
                 for (int rr = tid; rr < seen_end; rr += NT) {
                     const int e = edge_flat(ord[rr]);
@@ -1052,7 +1052,7 @@ __device__ void rips_sweep(int n, int E, int Ev, const u16* rank, const u16* ord
                         for (int c = 0; c < W; ++c) kw[j].w[c] = *reinterpret_cast<const WT*>(list + ES * jj + 4 + c * (int)sizeof(WT));
                     }
 #pragma unroll 4
-                    for (int rr = tid; rr < r0 + clen; rr += NT) {
+                    for (int rr = tid; rr < (r0 + clen < Ev ? r0 + clen : Ev); rr += NT) {
                         const int e = edge_flat(ord[rr]);
                         Psi<W, WT> p = psi[e];
                         bool changed = false;
@@ -1236,6 +1236,13 @@ __device__ void rips_dm_window(unsigned char* smem, const int win, const double*
     if (tid == 0) { out.h0_cnt[win] = k0; out.h1_cnt[win] = k1; out.status[win] = st; }
 }
 
+#ifdef TDA_DEBUG_PTS
+__device__ double g_dbg[2048];
+extern "C" __attribute__((visibility("default"))) int tda_debug_read(double* out)
+{
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_dbg), sizeof(double) * 2048) != hipSuccess;
+}
+#endif
 // ---------------------------------------------------------------------------------
 // point-cloud flavour (audio): LDS = [S | psi] [ord] [rank] [pts f64] [misc]
 // mode 0: Takens embedding of a window (utils.py:107-116) + min-max (utils.py:127-130)
@@ -1355,6 +1362,9 @@ __device__ void rips_cloud_window(unsigned char* smem, const int win, const doub
         }
         __syncthreads();
     }
+#ifdef TDA_DEBUG_PTS
+    for (int idx = tid; idx < P * dim; idx += NT) g_dbg[idx] = pts[idx];
+#endif
     // P0. keys
     const int E = tri2(P);
     const u32 tkey = f32_sortable(thresh);
@@ -1388,6 +1398,10 @@ __device__ void rips_cloud_window(unsigned char* smem, const int win, const doub
     PROF_COUNT(8, 1);
     PROF_COUNT(9, E);
     PROF_FLUSH();
+#ifdef TDA_DEBUG_PTS
+    __syncthreads();
+    for (int idx = tid; idx < P * dim; idx += NT) g_dbg[1024 + idx] = pts[idx];
+#endif
     if (tid == 0) { out.h0_cnt[win] = k0; out.h1_cnt[win] = k1; out.status[win] = st; }
 }
 

@@ -277,6 +277,35 @@ def test_cloud_rips_matches_reference_preprocessing(ctx, golden):
         assert st[0] == 0 and _same_multiset(h0[0], o[0]) and _same_multiset(h1[0], o[1]), name
 
 
+def test_small_clouds_short_last_chunk(ctx):
+    """Clouds whose edge list ends inside a sweep chunk (fewer edges than one chunk, or a short last chunk),
+    every class-vector width.  tests/golden/regress_cloud_p31.npy is a 31-point cloud on which the table
+    rewrite once walked past the end of the edge list (found by tools/stress_parity.py)."""
+    import os
+    pcs = [np.load(os.path.join(os.path.dirname(__file__), "golden", "regress_cloud_p31.npy"))]
+    rng = np.random.default_rng(77)
+    for P in (3, 4, 7, 12, 20, 31, 32, 33, 40, 46):
+        for rep in range(4):
+            pc = rng.random((P, 3))
+            if rep == 3:
+                pc[P // 2:] = pc[:P - P // 2]                  # duplicate points: zero-length edges
+            pcs.append(pc)
+    try:
+        for words in ((2, 1), (1, 1), (2, 2)):
+            ctx.set_class_words(*words)
+            for i, pc in enumerate(pcs):
+                h0, h1, st = engine.cloud_rips_batch(pc[None], normalise=True, thresh=2.0, h1_cap=4096, ctx=ctx)
+                dm = port.cloud_dm(port.minmax_normalise(pc)).astype(np.float32)
+                o = port.rips_f32(dm, thresh=2.0)
+                assert (st[0] & ~4) == 0
+                assert _same_multiset(h0[0], o[0]) and _same_multiset(h1[0], o[1]), (words, i, len(pc))
+                if len(pc) <= 12:
+                    b = brute.rips_brute(dm.astype(np.float64), 2.0)
+                    assert _same_multiset(h1[0], b[1]), (words, i)
+    finally:
+        ctx.set_class_words(2, 1)
+
+
 # ------------------------------------------------------------------ features
 def test_features_vs_reference_golden_and_oracle(ctx, golden):
     names = ["mixed", "single", "empty_finite", "zero_pers", "f32vals", "big"]
