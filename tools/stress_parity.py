@@ -83,6 +83,32 @@ for words in ((2, 1), (1, 1)):
                 np.savez(f"gpurun_out/fail_cloud_{P}_{rep}.npz", pc=pc, h0=h0[0], h1=h1[0], o0=o[0], o1=o[1])
             bad += not ok
     print("class words", words, "mismatches so far:", bad, flush=True)
+# Wasserstein: quantised coordinates (many equal costs), near-diagonal points, empty / single-row diagrams, equal
+# births (1-D path) and general position, sizes up to the buffers the pipeline uses
+wbad = 0
+for rnd in range(4 * SCALE):
+    As, Bs = [], []
+    for k in range(250):
+        m, n = int(rng.integers(0, 64)), int(rng.integers(0, 128))
+        q = (0, 4, 16, 1 << 20)[k % 4]                          # 0: continuous
+        def dgm(sz, equal_birth):
+            x = rng.random((sz, 2))
+            if q: x = np.round(x * q) / q
+            x = np.sort(x, axis=1)
+            if k % 5 == 0: x[:, 1] = x[:, 0] + x[:, 1] * 1e-3       # hugging the diagonal
+            if equal_birth: x[:, 0] = 0.0; x = x[np.argsort(x[:, 1], kind="stable")]
+            return x
+        eb = k % 3 == 0
+        As.append(dgm(m, eb)); Bs.append(dgm(n, eb))
+    ra, ca = engine.pack_diagrams(As, cap=64); rb, cb = engine.pack_diagrams(Bs, cap=128)
+    out, st = engine.wasserstein_batch(ra, ca, rb, cb, ctx=ctx, want_status=True)
+    ref = np.array([brute.safe_wasserstein_oracle(a, b) for a, b in zip(As, Bs)])
+    err = np.abs(out - ref)
+    nb = int((err > 1e-9).sum() + (st != 0).sum())
+    if nb: print("FAIL wasserstein round", rnd, "max err", err.max(), "at", int(err.argmax()), "status!=0:", int((st != 0).sum()), flush=True)
+    wbad += nb
+print("wasserstein mismatches:", wbad, flush=True)
+bad += wbad
 ctx.set_class_words(2, 1)
 print("STRESS", "OK" if bad == 0 else f"FAILED ({bad})")
 sys.exit(1 if bad else 0)
