@@ -205,7 +205,9 @@ class Lanes:
                 if self.before_step is not None:
                     self.before_step(i)
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g, stream=st):
+                # thread_local: calls made by other threads meanwhile (e.g. the event queries of the RCCL watchdog
+                # at N > 1) must not invalidate the capture
+                with torch.cuda.graph(g, stream=st, capture_error_mode="thread_local"):
                     run_step(eeg_win, audio_win, ws, ctx=ctx, max_lag=max_lag, retry=retry)
                 self.graphs[key] = g
             with torch.cuda.stream(st):
