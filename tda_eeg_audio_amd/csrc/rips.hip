@@ -165,6 +165,34 @@ __device__ __forceinline__ int edge_row(int e)
 }
 
 // ---------------------------------------------------------------------------------
+// Workgroup-wide OR / AND of a predicate with ONE barrier (the library's __syncthreads_or / _and take three
+// and an LDS atomic).  Every wave leaves the verdict of its ballot in its slot, one barrier, everybody reads the
+// slots.  Two sets of slots are used alternately: a wave writes set s again only two votes later, after it has
+// passed the barrier of the vote in between -- which no wave reaches before it has read set s.  All threads of
+// the workgroup must take part in every vote (uniform control flow), as with __syncthreads.
+// ---------------------------------------------------------------------------------
+struct WgVote {
+    u32* slots;      // 16 u32 in LDS, 16-byte aligned
+    int parity;
+};
+template <int NT>
+__device__ __forceinline__ bool wg_any(WgVote& v, bool p)
+{
+    static_assert(NT == 256 || NT == 512, "slots are read as one or two 16-byte words");
+    const bool w = __ballot(p) != 0ull;
+    u32* s = v.slots + 8 * v.parity;
+    if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = w ? 1u : 0u;
+    __syncthreads();
+    v.parity ^= 1;
+    const uint4 x = *reinterpret_cast<const uint4*>(s);
+    u32 r = x.x | x.y | x.z | x.w;
+    if (NT == 512) { const uint4 y = *reinterpret_cast<const uint4*>(s + 4); r |= y.x | y.y | y.z | y.w; }
+    return r != 0u;
+}
+template <int NT>
+__device__ __forceinline__ bool wg_all(WgVote& v, bool p) { return !wg_any<NT>(v, !p); }
+
+// ---------------------------------------------------------------------------------
 // P1: stable LSD radix sort of the edges by their float32 length, in LDS, by the whole workgroup.
 // The keys stay where they are (key32[e], e = flat edge index tri2(a)+b); what moves is the 16-bit
 // edge (a << 8 | b), ping-ponging between two arrays, four key bits per pass.  The edges start in
@@ -195,7 +223,7 @@ __device__ __forceinline__ int edge_flat(u32 pk) { return tri2((int)(pk >> 8)) +
 // key32: E keys; ia: E edges in flat order on entry; ib: second array; cnt: 16 * NT u16; wsum: NT/64 ints.
 // Returns the array that holds the sorted edges.
 template <int NT>
-__device__ u16* radix_sort_lds(const u32* key32, u16* ia, u16* ib, u16* cnt, int* wsum, int E)
+__device__ u16* radix_sort_lds(const u32* key32, u16* ia, u16* ib, u16* cnt, int* wsum, u32* vote_slots, int E)
 {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int B = (E + NT - 1) / NT;                  // positions per thread (<= 32)
@@ -203,6 +231,7 @@ __device__ u16* radix_sort_lds(const u32* key32, u16* ia, u16* ib, u16* cnt, int
     u16* cur = ia;
     u16* nxt = ib;
     if (E < 2) return cur;
+    WgVote vote{vote_slots, 0};
     for (int shift = 0; shift < 32; shift += 4) {
         // ---- count ----
         u64 c0 = 0ull, c1 = 0ull;                     // digits 0..7 / 8..15, 8 bits each
@@ -217,7 +246,7 @@ __device__ u16* radix_sort_lds(const u32* key32, u16* ia, u16* ib, u16* cnt, int
         }
 #pragma unroll
         for (int d = 0; d < 16; ++d) cnt[d * NT + tid] = (u16)(((d < 8 ? c0 : c1) >> (8 * (d & 7))) & 255ull);
-        if (__syncthreads_and(same ? 1 : 0)) continue;           // every edge has this digit: nothing moves
+        if (wg_all<NT>(vote, same)) continue;                    // every edge has this digit: nothing moves
         // ---- scan: entries [16 t, 16 t + 16) of the (digit-major, thread-minor) table ----
         int loc[16], s = 0;
 #pragma unroll
@@ -326,7 +355,7 @@ struct RipsLayout {
 // misc block (byte offsets inside off_misc); the class tables at its end are sized by the variant
 #define MISC_COMP 0                                          // int comp[128] / u32 vmax[128] (before the sweep)
 #define MISC_CAND 512                                        // u64 cand[16]
-#define MISC_WV (512 + 128)                                  // 64 B scratch
+#define MISC_WV (512 + 128)                                  // 64 B: wave sums of the sort, then the vote slots of the sweep
 #define MISC_MIN (512 + 192)                                 // u32[4]: reductions; list count / earliest key
 #define MISC_DONE (512 + 208)                                // u8 done[NT_MAX]
 #define MISC_SORTCNT (512 + 224)                             // sort phase only: u16 cnt[16 * NT] (over the sweep's part)
@@ -368,6 +397,7 @@ __device__ void rips_sweep(int n, int E, int Ev, const u16* rank, const u16* ord
     }
     __syncthreads();
 
+    WgVote vote{reinterpret_cast<u32*>(misc + MISC_WV), 0};      // (the sort's wave sums are done with)
     WT alive[W];
 #pragma unroll
     for (int c = 0; c < W; ++c) alive[c] = 0;
@@ -484,7 +514,7 @@ __device__ void rips_sweep(int n, int E, int Ev, const u16* rank, const u16* ord
                         if (ca == cb2) live = false;                          // ends already joined: a birth
                         else { atomicMin(&bbest[ca], (u32)tid); atomicMin(&bbest[cb2], (u32)tid); }
                     }
-                    if (!__syncthreads_or(live ? 1 : 0)) break;
+                    if (!wg_any<NT>(vote, live)) break;
                     if (live && (bbest[ca] == (u32)tid || bbest[cb2] == (u32)tid)) { picked = true; live = false; }
                     // every label with a best edge points at the label on the other side of it
                     if (tid < 128) {
@@ -503,7 +533,7 @@ __device__ void rips_sweep(int n, int E, int Ev, const u16* rank, const u16* ord
                     for (int it = 0; it < 8; ++it) {                           // pointer jumping (any mix of old and new
                         bool moved = false;                                    // values still points at an ancestor)
                         if (tid < 128) { const int pp = bpar[tid], gp = bpar[pp]; if (gp != pp) { bpar[tid] = gp; moved = true; } }
-                        if (!__syncthreads_or(moved ? 1 : 0)) break;
+                        if (!wg_any<NT>(vote, moved)) break;
                     }
                     // (the barriers of the pointer jumping separate this round's reads of bbest / bcomp from these writes)
                     if (tid < 128) { bcomp[tid] = bpar[bcomp[tid]]; bbest[tid] = 0xffffffffu; }
@@ -700,7 +730,7 @@ __device__ void rips_sweep(int n, int E, int Ev, const u16* rank, const u16* ord
         }
         if (!pending) done[tid] = 1;        // candidates, idle lanes and the lanes above are settled
         // rounds for the rest: a lane is ready when both dependencies are settled
-        while (__syncthreads_or(pending ? 1 : 0)) {
+        while (wg_any<NT>(vote, pending)) {
             bool ready = false;
             if (pending) ready = (q1 < 0 || done[q1]) && (q2 < 0 || done[q2]);
             __syncthreads();                 // all flag reads of this round precede its flag writes
@@ -1104,7 +1134,7 @@ __device__ void rips_sweep(int n, int E, int Ev, const u16* rank, const u16* ord
                 rr += NT;
             }
             cov_next = rr;
-            if (__syncthreads_and(covered ? 1 : 0)) { PROF_COUNT(25, 1); PROF_MARK(7); break; }
+            if (wg_all<NT>(vote, covered)) { PROF_COUNT(25, 1); PROF_MARK(7); break; }
         }
         PROF_MARK(7);
     }
@@ -1220,7 +1250,7 @@ __device__ void rips_dm_window(unsigned char* smem, const int win, const double*
     __syncthreads();
     const int Ev = count_effective_edges<NT>(key32, E, n, tkey, vmax, red);
     PROF_MARK(0);
-    const u16* sorted = radix_sort_lds<NT>(key32, ia, ib, cnt, wsum, E);
+    const u16* sorted = radix_sort_lds<NT>(key32, ia, ib, cnt, wsum, reinterpret_cast<u32*>(misc + MISC_CAND), E);
     PROF_MARK(1);
     unpack_sorted<NT, true, false>(sorted, key32, E, Ev, rank, ord, skey);
     PROF_MARK(2);
@@ -1385,7 +1415,7 @@ __device__ void rips_cloud_window(unsigned char* smem, const int win, const doub
     __syncthreads();
     const int Ev = count_effective_edges<NT>(key32, E, P, tkey, vmax, red);
     PROF_MARK(0);
-    const u16* sorted = radix_sort_lds<NT>(key32, ia, ib, cnt, wsum, E);
+    const u16* sorted = radix_sort_lds<NT>(key32, ia, ib, cnt, wsum, reinterpret_cast<u32*>(misc + MISC_CAND), E);
     PROF_MARK(1);
     unpack_sorted<NT, false, (sizeof(WT) * W < 8)>(sorted, key32, E, Ev, rank, ord, nullptr);
     PROF_MARK(2);
