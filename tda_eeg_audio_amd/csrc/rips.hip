@@ -405,6 +405,7 @@ __device__ void rips_sweep(int n, int E, int Ev, const u16* rank, const u16* ord
     int compA = lane, compB = lane + 64;     // component labels of vertices lane / lane+64 (used by wave 0)
 
     int clen = NT;
+    int ordcls = 0;                              // wave 0, one class word: lane i holds the i-th oldest class alive
     int cov_next = tid;                          // coverage check: first edge of this thread's residue class not yet seen covered
     PROF_RESUME();
     for (int r0 = 0; r0 < Ev && !status; r0 += clen) {
@@ -667,6 +668,13 @@ __device__ void rips_sweep(int n, int E, int Ev, const u16* rank, const u16* ord
                 psi[tab] = nv;
                 brank[idx] = r;
                 bkey[idx] = mykey;
+            }
+            // one class word: wave 0 keeps the classes alive in birth order, one per lane, so that the elder rule of the
+            // kill reduction is a ballot and a count of leading zeros.  The births of a chunk come in rank order and
+            // are younger than everything alive: they are appended
+            if (W == 1 && wave == 0 && btot > 0) {
+                const int nal = __builtin_popcountll((u64)alive[0]);
+                if (lane >= nal && lane < nal + btot) ordcls = (int)freebits[lane - nal];
             }
             // the btot lowest free class indices are in use now (every thread updates its copy)
             int left = btot;
@@ -931,6 +939,7 @@ __device__ void rips_sweep(int n, int E, int Ev, const u16* rank, const u16* ord
                 }
                 // FTAB: lane j keeps kill j -- the image of its class under all LATER kills (composed
                 // substitution), the rank of the killing edge and the birth length
+                int nalive0 = W == 1 ? __builtin_popcountll((u64)alive[0]) : 0;     // lanes of `ordcls` in use
                 Psi<W, WT> vimg = pzero<W, WT>();
                 u32 mycode = 0u, myrk = 0u;
                 float mybirth = 0.f;
@@ -956,17 +965,33 @@ __device__ void rips_sweep(int n, int E, int Ev, const u16* rank, const u16* ord
                     }
                     const int rk = r0 + (int)(best >> 8);
                     // youngest class of wv (elder rule)
-                    int candv = -1, cwl = 0;
-                    float byl = 0.f;
+                    int ybit, ycw;
+                    float ybirth;
+                    if (W == 1) {
+                        // lanes hold the classes alive in birth order: the youngest member is the highest lane set
+                        const u64 ob = __ballot(lane < nalive0 && (((u64)wv.w[0] >> ordcls) & 1ull));
+                        if (!ob) { status |= TDA_WIN_CLASS_OVERFLOW; break; }                    // cannot happen: never spin
+                        const int opos = 63 - __builtin_clzll(ob);
+                        ybit = (int)rl32((u32)ordcls, opos);
+                        ycw = 0;
+                        ybirth = __uint_as_float(rl32(__float_as_uint(bky[0]), ybit));
+                        // the class leaves the order: the younger ones move down one lane
+                        const int up = __builtin_amdgcn_update_dpp(0, ordcls, 0x130, 0xF, 0xF, true);     // wave_shl:1 = lane + 1
+                        if (lane >= opos) ordcls = up;
+                        --nalive0;
+                    } else {
+                        int candv = -1, cwl = 0;
+                        float byl = 0.f;
 #pragma unroll
-                    for (int c = 0; c < W; ++c)
-                        if (lane < WB && ((wv.w[c] >> lb) & (WT)1) && brk[c] > candv) { candv = brk[c]; cwl = c; byl = bky[c]; }
-                    const int bestr = wave_max_i32_dpp(candv);
-                    const u64 ybal = __ballot(candv == bestr && candv >= 0);                     // birth ranks are distinct
-                    if (!ybal) { status |= TDA_WIN_CLASS_OVERFLOW; break; }                      // cannot happen: never spin
-                    const int ybit = __builtin_ctzll(ybal);
-                    const int ycw = (int)rl32((u32)cwl, ybit);
-                    const float ybirth = __uint_as_float(rl32(__float_as_uint(byl), ybit));
+                        for (int c = 0; c < W; ++c)
+                            if (lane < WB && ((wv.w[c] >> lb) & (WT)1) && brk[c] > candv) { candv = brk[c]; cwl = c; byl = bky[c]; }
+                        const int bestr = wave_max_i32_dpp(candv);
+                        const u64 ybal = __ballot(candv == bestr && candv >= 0);                 // birth ranks are distinct
+                        if (!ybal) { status |= TDA_WIN_CLASS_OVERFLOW; break; }                  // cannot happen: never spin
+                        ybit = __builtin_ctzll(ybal);
+                        ycw = (int)rl32((u32)cwl, ybit);
+                        ybirth = __uint_as_float(rl32(__float_as_uint(byl), ybit));
+                    }
                     if (FTAB) {
                         WT sel = 0;
 #pragma unroll
