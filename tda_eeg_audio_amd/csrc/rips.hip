@@ -852,15 +852,16 @@ __device__ void rips_sweep(int n, int E, int Ev, const u16* rank, const u16* ord
             if (apparent) {
                 base = psi[tab];
                 Psi<W, WT> prev = pzero<W, WT>();                    // a repeated vector reduces to zero: skip it
+                // (64 vertices per word: the four triangles of a trip may come from anywhere in it)
 #pragma unroll
-                for (int wi = 0; wi < 2 * NVW; ++wi) {
-                    u32 mm = mws[wi];
-                    const int vbase = 32 * wi;
+                for (int wi = 0; wi < NVW; ++wi) {
+                    u64 mm = (u64)mws[2 * wi] | ((u64)mws[2 * wi + 1] << 32);
+                    const int vbase = 64 * wi;
                     while (mm) {
-                        const int v0 = vbase + __builtin_ctz(mm); mm &= mm - 1u;
-                        const bool ok1 = mm != 0u; const int v1 = ok1 ? vbase + __builtin_ctz(mm) : v0; mm &= mm - 1u;
-                        const bool ok2 = mm != 0u; const int v2 = ok2 ? vbase + __builtin_ctz(mm) : v0; mm &= mm - 1u;
-                        const bool ok3 = mm != 0u; const int v3 = ok3 ? vbase + __builtin_ctz(mm) : v0; mm &= mm - 1u;
+                        const int v0 = vbase + __builtin_ctzll(mm); mm &= mm - 1ull;
+                        const bool ok1 = mm != 0ull; const int v1 = ok1 ? vbase + __builtin_ctzll(mm) : v0; mm &= mm - 1ull;
+                        const bool ok2 = mm != 0ull; const int v2 = ok2 ? vbase + __builtin_ctzll(mm) : v0; mm &= mm - 1ull;
+                        const bool ok3 = mm != 0ull; const int v3 = ok3 ? vbase + __builtin_ctzll(mm) : v0; mm &= mm - 1ull;
 #define TDA_IDX_(v, ja, jb)                                                       \
                         const int t##ja = (int)(__umul24((u32)(v), (u32)((v) - 1)) >> 1); \
                         const int ja = (v) < a ? ta_ + (v) : t##ja + a;                    \
