@@ -278,42 +278,6 @@ __device__ u16* radix_sort_lds(const u32* key32, u16* ia, u16* ib, u16* cnt, int
     return cur;
 }
 
-// Scan the remaining triangles (a,b,v), v in one 32-bit mask word (vertices vbase..vbase+31), four
-// per trip (all eight LDS reads are issued before the first test).  Returns true at the first
-// non-trivial boundary class psi[a,v]^psi[b,v]^base and leaves the word positioned just after it.
-template <int W, typename WT>
-__device__ __forceinline__ bool scan_word(u32& mw, const int vbase, const Psi<W, WT>* psi, const Psi<W, WT> base, int a, int b,
-                                          int ta, int tb, int& cur_v, int& ia, int& ib)
-{
-    while (mw) {
-        u32 mm = mw;
-        const int v0 = vbase + __builtin_ctz(mm); mm &= mm - 1u;
-        const bool ok1 = mm != 0u; const int v1 = ok1 ? vbase + __builtin_ctz(mm) : v0; mm &= mm - 1u;
-        const bool ok2 = mm != 0u; const int v2 = ok2 ? vbase + __builtin_ctz(mm) : v0; mm &= mm - 1u;
-        const bool ok3 = mm != 0u; const int v3 = ok3 ? vbase + __builtin_ctz(mm) : v0; mm &= mm - 1u;
-#define TDA_IDX_(v, ja, jb)                                               \
-        const int t##ja = (int)(__umul24((u32)(v), (u32)((v) - 1)) >> 1); \
-        const int ja = (v) < a ? ta + (v) : t##ja + a;                    \
-        const int jb = (v) < b ? tb + (v) : t##ja + b;
-        TDA_IDX_(v0, ja0, jb0) TDA_IDX_(v1, ja1, jb1) TDA_IDX_(v2, ja2, jb2) TDA_IDX_(v3, ja3, jb3)
-#undef TDA_IDX_
-        const Psi<W, WT> p0 = psi[ja0], q0 = psi[jb0], p1 = psi[ja1], q1 = psi[jb1];
-        const Psi<W, WT> p2 = psi[ja2], q2 = psi[jb2], p3 = psi[ja3], q3 = psi[jb3];
-        const bool n0 = pnz(pxor(pxor(p0, q0), base));
-        const bool n1 = ok1 && pnz(pxor(pxor(p1, q1), base));
-        const bool n2 = ok2 && pnz(pxor(pxor(p2, q2), base));
-        const bool n3 = ok3 && pnz(pxor(pxor(p3, q3), base));
-        if (!(n0 || n1 || n2 || n3)) { mw = mm; continue; }
-        if (n0) { cur_v = v0; ia = ja0; ib = jb0; }
-        else if (n1) { cur_v = v1; ia = ja1; ib = jb1; }
-        else if (n2) { cur_v = v2; ia = ja2; ib = jb2; }
-        else { cur_v = v3; ia = ja3; ib = jb3; }
-        mw &= ~((2u << (cur_v - vbase)) - 1u);      // everything up to the hit is consumed
-        return true;
-    }
-    return false;
-}
-
 // Effective threshold = min(thresh, enclosing radius).  At the enclosing radius
 // r_enc = min_v max_u d(v,u) some vertex is adjacent to every other one, the complex is a cone and
 // stays one: H0 is connected, every H1 class is dead and every later edge is killed at once by the
@@ -531,12 +495,18 @@ __device__ void rips_sweep(int n, int E, int Ev, const u16* rank, const u16* ord
                         bpar[tid] = pp;
                     }
                     __syncthreads();
-                    for (int it = 0; it < 8; ++it) {                           // pointer jumping (any mix of old and new
-                        bool moved = false;                                    // values still points at an ancestor)
-                        if (tid < 128) { const int pp = bpar[tid], gp = bpar[pp]; if (gp != pp) { bpar[tid] = gp; moved = true; } }
-                        if (!wg_any<NT>(vote, moved)) break;
+                    // pointer jumping by ONE wave, two labels per lane: the LDS serves the accesses of a wave in program
+                    // order, so the trips need no barrier (with two waves every trip cost one)
+                    if (wave == 0) {
+                        for (int it = 0; it < 8; ++it) {
+                            const int p0 = bpar[lane], p1 = bpar[64 + lane];
+                            const int g0 = bpar[p0], g1 = bpar[p1];
+                            if (__ballot(g0 != p0 || g1 != p1) == 0ull) break;
+                            bpar[lane] = g0; bpar[64 + lane] = g1;
+                        }
                     }
-                    // (the barriers of the pointer jumping separate this round's reads of bbest / bcomp from these writes)
+                    __syncthreads();
+                    // (the two barriers above separate this round's reads of bbest / bcomp from these writes)
                     if (tid < 128) { bcomp[tid] = bpar[bcomp[tid]]; bbest[tid] = 0xffffffffu; }
                     __syncthreads();
                 }
