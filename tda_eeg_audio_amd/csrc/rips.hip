@@ -464,15 +464,17 @@ __device__ void rips_sweep(int n, int E, int Ev, const u16* rank, const u16* ord
         int qpar = NT;                                           // cut of the chunk found by the parallel path
         if (par) {
             int* bcomp = reinterpret_cast<int*>(misc + MISC_LIST + 1024);    // [128] label of every vertex
-            u32* bbest = reinterpret_cast<u32*>(bcomp + 128);                // [128] earliest candidate at a label
-            int* bpar = reinterpret_cast<int*>(bcomp + 256);                 // [128] contraction pointers
+            u32* bbest2 = reinterpret_cast<u32*>(bcomp + 128);               // [2][128] earliest candidate at a label,
+            int* bpar = reinterpret_cast<int*>(bcomp + 384);                 //          one set per round parity
+                                                                             // [128] contraction pointers
             // classify the candidates at chunk positions < limit, starting from the labels of the chunk start
             auto rounds = [&](int limit) {
                 if (wave == 0) { bcomp[lane] = lblA0; bcomp[64 + lane] = lblB0; }
-                if (tid < 128) bbest[tid] = 0xffffffffu;
+                if (tid < 256) bbest2[tid] = 0xffffffffu;
                 __syncthreads();
                 bool live = is_cand && tid < limit, picked = false;
                 for (int round = 0; round < 64; ++round) {
+                    u32* bbest = bbest2 + 128 * (round & 1);
                     int ca = 0, cb2 = 0;
                     if (live) {
                         ca = bcomp[a]; cb2 = bcomp[b];
@@ -481,33 +483,38 @@ __device__ void rips_sweep(int n, int E, int Ev, const u16* rank, const u16* ord
                     }
                     if (!wg_any<NT>(vote, live)) break;
                     if (live && (bbest[ca] == (u32)tid || bbest[cb2] == (u32)tid)) { picked = true; live = false; }
-                    // every label with a best edge points at the label on the other side of it
-                    if (tid < 128) {
-                        int pp = tid;
-                        const u32 bp = bbest[tid];
-                        if (bp != 0xffffffffu) {
-                            const u32 pk = ord[r0 + (int)bp];
-                            const int oa = bcomp[pk >> 8], ob = bcomp[pk & 255u];
-                            pp = oa == tid ? ob : oa;
-                            // two labels that picked the same edge would point at each other: the smaller one is the root
-                            if (bbest[pp] == bp && tid < pp) pp = tid;
-                        }
-                        bpar[tid] = pp;
-                    }
-                    __syncthreads();
-                    // pointer jumping by ONE wave, two labels per lane: the LDS serves the accesses of a wave in program
-                    // order, so the trips need no barrier (with two waves every trip cost one)
+                    // The contraction is the business of ONE wave, two labels per lane, and needs no barrier inside:
+                    // the LDS serves the accesses of a wave in program order.  Nobody else touches bcomp / bpar between
+                    // the vote above and the barrier below; this round's bbest is still being read by the others, so
+                    // it is left alone and the OTHER set (last read a round ago) is wiped for the next round.
                     if (wave == 0) {
-                        for (int it = 0; it < 8; ++it) {
+                        int pp[2];
+#pragma unroll
+                        for (int h = 0; h < 2; ++h) {
+                            const int me = lane + 64 * h;
+                            pp[h] = me;
+                            const u32 bp = bbest[me];
+                            if (bp != 0xffffffffu) {                          // point at the label on the other side of my edge
+                                const u32 pk = ord[r0 + (int)bp];
+                                const int oa = bcomp[pk >> 8], ob = bcomp[pk & 255u];
+                                pp[h] = oa == me ? ob : oa;
+                                // two labels that picked the same edge would point at each other: the smaller one is the root
+                                if (bbest[pp[h]] == bp && me < pp[h]) pp[h] = me;
+                            }
+                        }
+                        bpar[lane] = pp[0]; bpar[64 + lane] = pp[1];
+                        for (int it = 0; it < 8; ++it) {                      // pointer jumping
                             const int p0 = bpar[lane], p1 = bpar[64 + lane];
                             const int g0 = bpar[p0], g1 = bpar[p1];
                             if (__ballot(g0 != p0 || g1 != p1) == 0ull) break;
                             bpar[lane] = g0; bpar[64 + lane] = g1;
                         }
+                        const int c0 = bcomp[lane], c1 = bcomp[64 + lane];
+                        const int n0 = bpar[c0], n1 = bpar[c1];
+                        bcomp[lane] = n0; bcomp[64 + lane] = n1;
+                        u32* other = bbest2 + 128 * ((round + 1) & 1);
+                        other[lane] = 0xffffffffu; other[64 + lane] = 0xffffffffu;
                     }
-                    __syncthreads();
-                    // (the two barriers above separate this round's reads of bbest / bcomp from these writes)
-                    if (tid < 128) { bcomp[tid] = bpar[bcomp[tid]]; bbest[tid] = 0xffffffffu; }
                     __syncthreads();
                 }
                 const u64 mb = __ballot(picked);
