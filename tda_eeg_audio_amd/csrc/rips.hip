@@ -1412,8 +1412,20 @@ __device__ void rips_cloud_window(unsigned char* smem, const int win, const doub
         const u32 sk = f32_sortable(kf(0, a, b));
         key32[e] = sk;
         ia[e] = (u16)((a << 8) | b);
-        atomicMax(&vmax[a], sk);
-        atomicMax(&vmax[b], sk);
+        atomicMax(&vmax[b], sk);          // (consecutive lanes: consecutive b, no conflict)
+    }
+    __syncthreads();
+    // The row part of max_u d(v,u): the lanes of a wave sit in one or two rows, so an atomic per edge would hit one
+    // address 64 times.  NT / 128 threads per vertex walk the finished row instead, a slice each.
+    {
+        constexpr int TPV = NT / 128;
+        const int v = tid / TPV, part = tid - v * TPV;
+        if (v < P) {
+            const int t0 = tri2(v);
+            u32 m = 0u;
+            for (int b = part; b < v; b += TPV) { const u32 k = key32[t0 + b]; m = k > m ? k : m; }
+            if (m) atomicMax(&vmax[v], m);
+        }
     }
     __syncthreads();
     const int Ev = count_effective_edges<NT>(key32, E, P, tkey, vmax, red);

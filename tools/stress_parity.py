@@ -104,10 +104,16 @@ for rnd in range(4 * SCALE):
     out, st = engine.wasserstein_batch(ra, ca, rb, cb, ctx=ctx, want_status=True)
     ref = np.array([brute.safe_wasserstein_oracle(a, b) for a, b in zip(As, Bs)])
     err = np.abs(out - ref)
-    nb = int((err > 1e-9).sum() + (st != 0).sum())
+    # 1e-7: a tenth of the north_star bar.  Coincident points of the two diagrams cost 0 or ~7e-9 depending on how the
+    # rounding residue of sklearn's |x|^2 - 2 x.y + |y|^2 falls (FMA or not in the BLAS behind it): not pinned
+    nb = int((err > 1e-7).sum() + (st != 0).sum())
+    if nb:
+        i = int(err.argmax())
+        os.makedirs("gpurun_out", exist_ok=True)
+        np.savez(f"gpurun_out/fail_wasserstein_{rnd}_{i}.npz", a=As[i], b=Bs[i], gpu=out[i], ref=ref[i])
     if nb: print("FAIL wasserstein round", rnd, "max err", err.max(), "at", int(err.argmax()), "status!=0:", int((st != 0).sum()), flush=True)
     wbad += nb
-print("wasserstein mismatches:", wbad, flush=True)
+print("wasserstein mismatches:", wbad, "(bar 1e-7)", flush=True)
 bad += wbad
 ctx.set_class_words(2, 1)
 print("STRESS", "OK" if bad == 0 else f"FAILED ({bad})")
