@@ -1302,13 +1302,31 @@ struct KeyFromPts {
     }
 };
 
+// The row part of max_u d(v,u) for a cloud: the lanes of a wave sit in one or two rows, so an atomic per edge would
+// hit one address 64 times.  NT / 128 threads per vertex walk the finished row instead, a slice each.  (Not inlined:
+// the point-cloud kernel sits at its register limit and the inlined loop tipped it into spilling.)
+template <int NT>
+__device__ __noinline__ void row_maxima(const u32* key32, u32* vmax, int P)
+{
+    constexpr int TPV = NT / 128;
+    const int tid = threadIdx.x;
+    const int v = tid / TPV, part = tid - v * TPV;
+    if (v < P) {
+        const int t0 = tri2(v);
+        u32 m = 0u;
+        for (int b = part; b < v; b += TPV) { const u32 k = key32[t0 + b]; m = k > m ? k : m; }
+        if (m) atomicMax(&vmax[v], m);
+    }
+}
+
 // Kernel shell shared by both flavours.  First pass: one workgroup per window.  Retry passes (wider
 // class vector) run a small grid that strides over the windows and only redoes the ones the previous
 // pass flagged, so a retry with nothing to do costs a few microseconds instead of n_win LDS-heavy
 // workgroup launches.
-// 64 classes: five 256-thread workgroups per CU = 5 waves per SIMD (102 VGPRs); 128 classes: four (128 VGPRs)
+// 64 and 128 classes: four waves per SIMD (128 VGPRs, no spills).  Five (96 VGPRs, 32 B of scratch per lane) paid while
+// the sweep spent its time at barriers; with the one-barrier votes four is 1 % faster end to end
 template <int NT, int NVW, int W, typename WT>
-__global__ void __launch_bounds__(NT, W == 1 ? 5 : (W == 2 ? 4 : 1))
+__global__ void __launch_bounds__(NT, W <= 2 ? 4 : 1)
 rips_dm_kernel(const double* __restrict__ dm, int n_win, int n, float thresh, int symmetrise, RipsLayout L,
                RipsOut out, int retry_only)
 {
@@ -1415,18 +1433,7 @@ __device__ void rips_cloud_window(unsigned char* smem, const int win, const doub
         atomicMax(&vmax[b], sk);          // (consecutive lanes: consecutive b, no conflict)
     }
     __syncthreads();
-    // The row part of max_u d(v,u): the lanes of a wave sit in one or two rows, so an atomic per edge would hit one
-    // address 64 times.  NT / 128 threads per vertex walk the finished row instead, a slice each.
-    {
-        constexpr int TPV = NT / 128;
-        const int v = tid / TPV, part = tid - v * TPV;
-        if (v < P) {
-            const int t0 = tri2(v);
-            u32 m = 0u;
-            for (int b = part; b < v; b += TPV) { const u32 k = key32[t0 + b]; m = k > m ? k : m; }
-            if (m) atomicMax(&vmax[v], m);
-        }
-    }
+    row_maxima<NT>(key32, vmax, P);
     __syncthreads();
     const int Ev = count_effective_edges<NT>(key32, E, P, tkey, vmax, red);
     PROF_MARK(0);
