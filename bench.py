@@ -1,24 +1,34 @@
 #!/usr/bin/env python3
 """
-bench.py -- headline benchmark: windows/sec end-to-end (dist -> Rips H0/H1 -> Wasserstein),
-47-channel EEG, on N MI355X (BASELINE.json `metric`).
+bench.py -- headline benchmark: windows/sec end-to-end (dist -> Rips H0/H1 -> Wasserstein), 47-channel EEG,
+on N MI355X (BASELINE.json `metric`).
 
-A step = ONE pass of the per-window hot path (tda_eeg_audio_amd/pipeline.py::run_step, the
-batched counterpart of scripts/tda_eeg_audio_comparison.py:77-122) over one batch of synthetic
-input already resident in HBM: per window corr->dist, Rips(EEG 47x47), Takens+Rips(audio),
-Wasserstein H0 and H1, H1 features, and the per-recording reductions.  Workload at N=1 =
-BASELINE.json configs[1]: 710 EEG windows of one band (+ the 710 matching audio windows).
-N>1: every rank gets its own 710 windows (weak scaling); the only collective is one all-gather
-of the per-recording result rows (RCCL over xGMI), inside the timed region.
+Workload (default `--workload corpus`, BASELINE.json configs[2] + configs[4]): the FIXED corpus of the reference --
+1,416 recordings x 5 bands x 15 selected windows = 106,200 (EEG window, audio window) pairs
+(scripts/tda_eeg_audio_comparison.py:39,77-80; results/eeg_audio_tda_detailed.csv has 7,080 rows of 15 windows) --
+dealt over the N ranks by whole recordings (dist.shard_recordings): STRONG scaling.  A step = ONE pass of the
+per-window hot path over the rank's share, resident in HBM (10 GB of float64 windows at N = 1, so nothing is served
+by the 256 MiB Infinity Cache): per window corr->dist, Rips(EEG 47x47), tau per recording-band, Takens+Rips(audio,
+23..123 points over the five bands), Wasserstein H0 and H1, H1/H0 features, the per-recording reductions, and ONE
+all-gather of the (n_rec, 5 x 48) result rows per pass (RCCL over xGMI) inside the timed region -- what replaces
+run_analysis' serial loop (cmp:131-138) and the partial-file merge of scripts/tda_eeg_classification_v2.py:608-638.
+`--workload batch710` is BASELINE.json configs[1]: 710 windows per band-batch, five distinct batches in rotation.
 
-Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (largest share of the
-step), with its average launch duration measured live with events on the launch stream.
-`cpu_baseline` times the CPU oracle (oracle/tda_oracle.c, kind "port", 1 core) on a bounded
-sample of the same workload.
+A second leg (`features_pass`, BASELINE.json configs[2]) times the EEG half alone on the min-equalised 39 windows
+per recording-band (276,120 windows -> the (1416, 220) feature matrix of v2:404-436,499-606, one all-gather).
+
+`python bench.py --gpus N` with WORLD_SIZE unset starts the N ranks itself (child processes, before this process
+touches a GPU); under torch.distributed.run it reads RANK / LOCAL_RANK / WORLD_SIZE.  Rank 0 prints ONE JSON line.
+`roofline` is for the dominant kernel (audio Rips), its launch duration measured live (kernel-stamped wall clock
+over every launch of the timed region + HIP events on the launch stream in the eager warm-up); `roofline_lds`
+restates the resource that actually binds it from the committed rocprofv3 PMC summary.  `cpu_baseline` times the
+CPU oracle (oracle/tda_oracle.c rebuilt -O3 -march=native on this host; kind "port") on a bounded sample of the same
+workload: one core and all the cores this process may use.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -31,79 +41,154 @@ sys.path.insert(0, ROOT)
 ALG_BYTES = {
     "corr_dist": 47 * 250 * 8 + 47 * 47 * 8,          # window in, distance matrix out (no corr copy)
     "rips_eeg": 47 * 47 * 8 + 1100,                   # 18.7 KB/window from the stored f64 matrix
-    "tau": 250 * 8 + 4,
+    "eeg_fused": 47 * 250 * 8 + 888 + 176,            # 95.1 KB/window: window in, diagrams + features out
     "rips_audio": 250 * 8 + 4 + 1500,                 # ~3.5 KB/window
-    "wasserstein_h0": 2700 + 8,                       # <= 2.7 KB/pair
-    "wasserstein_h1": 2700 + 8,
-    "features_eeg": 2 * (1100 + 88) + 2 * 22 * 8,
-    "features_audio": 1100 + 88,
-    "reduce": 2 * 8,
+    "wasserstein": 2700 + 8,                          # <= 2.7 KB/pair
 }
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 
 
-def main():
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--windows", type=int, default=710, help="windows per GPU per step (configs[1] = 710)")
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="corpus", choices=["corpus", "batch710"])
+    ap.add_argument("--recordings", type=int, default=1416, help="recordings of the corpus (README.md:7)")
     ap.add_argument("--windows-per-recording", type=int, default=15, help="cmp:39 MAX_WINDOWS")
-    ap.add_argument("--band", default="beta")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg")
+    ap.add_argument("--features-windows", type=int, default=39, help="v2 min-equalised windows per recording-band")
+    ap.add_argument("--features-steps", type=int, default=3, help="passes of the features leg (0 = skip)")
+    ap.add_argument("--cpu-seconds", type=float, default=24.0, help="budget of the cpu_baseline leg (both legs)")
     ap.add_argument("--no-cpu", action="store_true")
-    ap.add_argument("--no-graph", action="store_true", help="launch every step eagerly instead of replaying a HIP graph")
-    ap.add_argument("--no-defer", action="store_true",
-                    help="launch the widening passes of the Rips stages with every step instead of verify-then-publish")
+    ap.add_argument("--no-extras", action="store_true", help="skip the features / PCIe legs")
+    ap.add_argument("--no-graph", action="store_true", help="launch every step eagerly instead of replaying HIP graphs")
     ap.add_argument("--lanes", type=int, default=int(os.environ.get("TDA_LANES", "3")),
-                    help="batches in flight (pipeline.Lanes): 1 = strictly one step after the other")
+                    help="band batches in flight (pipeline.Lanes)")
+    ap.add_argument("--class-words", default=os.environ.get("TDA_CLASS_WORDS", "1,1"),
+                    help="first-pass class capacity (x64 bits for EEG, x32/x64 for audio); windows that need more are "
+                         "redone by the widening passes inside the same step and counted in windows_repaired")
     ap.add_argument("--share-gpu", action="store_true",
                     help="rehearsal only: every rank uses cuda:0 and the all-gather goes through gloo "
                          "(exercises the N>1 code path on a one-GPU box; numbers are meaningless)")
-    args = ap.parse_args()
+    ap.add_argument("--cpu-worker", default=None, help=argparse.SUPPRESS)     # internal: the cpu_baseline child process
+    return ap.parse_args()
+
+
+# ------------------------------------------------------------------------------------------------------------
+# N ranks from a plain `python bench.py --gpus N`: children are started BEFORE this process touches a GPU
+# ------------------------------------------------------------------------------------------------------------
+def self_launch(args):
+    import socket
+    import torch                                  # device_count() does not initialise the GPU on this image
+    n = args.gpus
+    if not args.share_gpu and torch.cuda.device_count() < n:
+        print(f"bench: --gpus {n} but only {torch.cuda.device_count()} GPU(s) visible", file=sys.stderr)
+        return 2
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    try:
+        while procs:
+            for p in list(procs):
+                code = p.poll()
+                if code is None:
+                    continue
+                procs.remove(p)
+                if code != 0:                     # one rank failed: the others would wait at a barrier for ever
+                    rc = rc or code
+                    for q in procs:
+                        q.terminate()
+            time.sleep(0.05)
+    except KeyboardInterrupt:
+        for q in procs:
+            q.terminate()
+        rc = 130
+    return rc
+
+
+def workload_spec(args):
+    """(recording ids, windows per recording-band in the end-to-end pass, label).  batch710: 47 recordings of 15
+    selected windows + one of 5 = the 710 windows of BASELINE.json configs[1] per band-batch."""
+    if args.workload == "batch710":
+        return 48, np.array([15] * 47 + [5]), "configs[1]"
+    return args.recordings, np.full(args.recordings, args.windows_per_recording), "configs[4]+configs[2]"
+
+
+def main():
+    args = parse_args()
+    if args.cpu_worker:
+        return cpu_worker(args.cpu_worker)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return self_launch(args)
 
     import torch
     import torch.distributed as dist
     from tda_eeg_audio_amd import _lib, pipeline, synth
     from tda_eeg_audio_amd import dist as tdist
 
-    if args.share_gpu:
-        os.environ["LOCAL_RANK_REAL"] = os.environ.get("LOCAL_RANK", "0")
     rank, world, local = tdist.init_from_env(backend="gloo" if args.share_gpu else None)
+    if world != args.gpus:
+        print(f"bench: WORLD_SIZE={world} but --gpus {args.gpus}", file=sys.stderr)
+        return 2
     if args.share_gpu:
         local = 0
-    assert world == args.gpus or world == 1, f"WORLD_SIZE={world} but --gpus {args.gpus}"
     if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+        print("bench.py needs an MI355X: the HIP path has no CPU fallback", file=sys.stderr)
+        return 2
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     ctx = _lib.get_ctx(local)
-    # first-pass class capacity: 64 bits for the EEG matrices (library default 128), 32 for the audio clouds.  No window
-    # of this workload needs more (tools/overflow_rate.py); any that did would be caught and repaired by the lanes.
-    if not os.environ.get("TDA_CLASS_WORDS"):
-        ctx.set_class_words(1, 1)
+    cw_dm, cw_cloud = (int(x) for x in args.class_words.split(","))
+    ctx.set_class_words(cw_dm, cw_cloud)
+    retry_ctr = torch.zeros(4, dtype=torch.int64, device=device)
+    ctx.set_retry_counter(retry_ctr.data_ptr())
 
-    n_win = args.windows
-    wpr = args.windows_per_recording
-    seg = list(range(0, n_win, wpr)) + [n_win]
-    seg_off = np.array(seg, np.int32)
-    n_seg = len(seg_off) - 1
-    # synthetic data of the named shape; each rank its own recordings (weak scaling)
-    eeg = synth.eeg_windows(n_win, seed=42 + 100000 * rank, windows_per_recording=wpr)
-    aud = synth.audio_windows(n_win, args.band, seed=4242 + 100000 * rank)
-    eeg_t = torch.from_numpy(eeg).to(device)
-    aud_t = torch.from_numpy(aud).to(device)
-    lanes = pipeline.Lanes(args.lanes, n_win, seg_off, device, graph=not args.no_graph, defer_retries=not args.no_defer)
-    shards = [np.arange(r * n_seg, (r + 1) * n_seg) for r in range(world)]
-    gather = (lambda res: tdist.all_gather_rows(res, shards[rank], shards, world * n_seg)) if world > 1 else None
+    # ---- the fixed workload and this rank's share of it (whole recordings; strong scaling) ----
+    n_rec, counts, cfg_label = workload_spec(args)
+    uniform = bool((counts == counts[0]).all())
+    wpr = int(counts[0])
+    shards = tdist.shard_recordings(counts, world)
+    mine = shards[rank]
+    bands = synth.BANDS
+    nb = len(bands)
+    t_gen = time.perf_counter()
+    if uniform:
+        eeg = synth.corpus_eeg_dev(mine, wpr, nb, device, seed=42)
+        aud_all = synth.corpus_audio(n_rec, wpr, bands, seed=4242)
+        aud = [torch.from_numpy(np.ascontiguousarray(aud_all[b][mine].reshape(-1, 250))).to(device) for b in bands]
+        runner = pipeline.CorpusPass(eeg, aud, wpr, device, ctx, depth=args.lanes, graph=not args.no_graph,
+                                     my_recs=mine, shards=shards, n_total=n_rec)
+    else:                                         # batch710: ragged last recording -> explicit group offsets
+        assert world == 1, "--workload batch710 is the one-GPU configuration"
+        seg_off = np.concatenate([[0], np.cumsum(counts)]).astype(np.int32)
+        eeg15 = synth.corpus_eeg_dev(np.arange(n_rec), 15, nb, device, seed=42)
+        aud_all = synth.corpus_audio(n_rec, 15, bands, seed=4242)
+        keep = np.concatenate([np.arange(r * 15, r * 15 + counts[r]) for r in range(n_rec)])
+        keep_t = torch.from_numpy(keep).to(device)
+        eeg = [e[keep_t].contiguous() for e in eeg15]
+        aud = [torch.from_numpy(np.ascontiguousarray(aud_all[b].reshape(-1, 250)[keep])).to(device) for b in bands]
+        del eeg15
+        runner = pipeline.CorpusPass(eeg, aud, None, device, ctx, depth=args.lanes, graph=not args.no_graph,
+                                     seg_off=seg_off)
+    torch.cuda.synchronize()
+    t_gen = time.perf_counter() - t_gen
+    n_win_batch = runner.n_win                    # windows per band-batch on this rank
+    total_pairs = int(counts.sum()) * nb          # window pairs of one pass of the whole job
+    lanes = runner.lanes
 
     # dominant kernel: rips_cloud_kernel (first pass of stage rips_audio).  The one-shot probe of the C ABI is armed
-    # before every launch (and before the capture of a lane's graph, so that it is baked into the replays): the kernel
-    # accumulates its own duration (first workgroup start .. last workgroup end, 100 MHz wall clock) in a per-lane
-    # device buffer; in the eager warm-up steps HIP events bracket the same launch on its stream.
+    # before every eager launch and before the capture of a band's graph, so that it is baked into the replays: the
+    # kernel accumulates its own duration (first workgroup start .. last workgroup end, 100 MHz wall clock) in a
+    # per-lane device buffer; in the eager warm-up pass HIP events bracket the same launch on its stream.
     DOM = "rips_audio"
-    span_init = np.zeros((lanes.depth, 4), np.int64)
-    spans = torch.from_numpy(span_init).to(device)
+    spans = torch.zeros((lanes.depth, 4), dtype=torch.int64, device=device)
     cur_events = [None]
 
     def arm(i):
@@ -111,58 +196,45 @@ def main():
         ctx.arm_probe(DOM, ev[0] if ev else None, ev[1] if ev else None, spans[i].data_ptr())
     lanes.before_step = arm
 
-    def step(timers=None):
-        # the inputs were uploaded before the loop and never change: no wait on the caller's stream
-        return lanes.submit(eeg_t, aud_t, ctx=ctx, timers=timers, post=gather, sync_inputs=False)
-
-    # ---- warm-up: eager steps with per-stage events (stage_ms, event_ms), then one more round of the lanes, which in
-    # graph mode captures each lane's step ----
-    n_eager = max(args.warmup, lanes.depth)
+    # ---- warm-up: one eager pass with per-stage events (stage_ms, event_ms), then W passes (the first captures) ----
     ev_log, probes = [], []
-    for _ in range(n_eager):
+    for b in range(nb):
         timers = {s: (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
                   for s in pipeline.STAGES}
         cur_events[0] = (ctx.new_event(), ctx.new_event())
         probes.append(cur_events[0])
-        out = step(timers)
+        lanes.submit(eeg[b], aud[b], ctx=ctx, timers=timers, sync_inputs=False, lane=b)
+        lanes.drain()
         ev_log.append(timers)
     cur_events[0] = None
+    torch.cuda.synchronize()
+    stage_ms = {s: sum(t[s][0].elapsed_time(t[s][1]) for t in ev_log) for s in pipeline.STAGES}    # per pass, bands alone
+    event_ms = [ctx.elapsed_ms(a, b) for a, b in probes]
     try:
-        for _ in range(lanes.depth):
-            out = step()
-        lanes.drain()
+        for _ in range(max(1, args.warmup)):
+            runner.step()
+        rows = runner.finish()
         torch.cuda.synchronize()
     except Exception as e:                      # graph capture refused on this stack: same steps, launched eagerly
         if not lanes.graph:
             raise
         print(f"bench: HIP graph capture failed ({type(e).__name__}: {e}); falling back to eager launches", file=sys.stderr)
         torch.cuda.synchronize()
-        lanes = pipeline.Lanes(args.lanes, n_win, seg_off, device, graph=False, defer_retries=not args.no_defer)
-        lanes.before_step = arm
-        for _ in range(lanes.depth):
-            out = step()
-        lanes.drain()
+        lanes.graph = False
+        lanes.graphs.clear()
+        for _ in range(max(1, args.warmup)):
+            runner.step()
+        rows = runner.finish()
         torch.cuda.synchronize()
+    bad = 0
     for ws in lanes.ws:
-        if not bool(((ws.eeg.status == 0) & ((ws.aud.status & ~4) == 0) & (ws.ws0 == 0) & (ws.ws1 == 0)).all()):
-            raise SystemExit("bench: a window reported a non-zero status (overflow / not converged)")
-    # the one HBM-streaming kernel of the step, corr_dist_kernel: HIP events around it in three steps that run alone
-    hbm_ms = []
-    for _ in range(3):
-        evs = (ctx.new_event(), ctx.new_event())
-        ctx.arm_probe("corr_dist", evs[0], evs[1])      # its own probe slot; the rips_audio probe stays armed too
-        lanes.submit(eeg_t, aud_t, ctx=ctx, timers={s: (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-                                                   for s in pipeline.STAGES}, post=None, sync_inputs=False)
-        lanes.drain()
-        torch.cuda.synchronize()
-        hbm_ms.append(ctx.elapsed_ms(*evs))
-    stage_ms = {s: 0.0 for s in pipeline.STAGES}
-    for evs in ev_log:
-        for s, (a, b) in evs.items():
-            stage_ms[s] += a.elapsed_time(b)
-    stage_ms = {s: v / n_eager for s, v in stage_ms.items()}
-    event_ms = sum(ctx.elapsed_ms(a, b) for a, b in probes) / n_eager
+        ok = (ws.eeg.status == 0) & ((ws.aud.status & ~4) == 0) & (ws.ws0 == 0) & (ws.ws1 == 0)
+        bad += int((~ok).sum().item())
+    if bad:
+        print(f"bench: {bad} windows reported a non-zero status (overflow beyond the ladder / not converged)", file=sys.stderr)
+        return 3
     sp_before = spans.cpu().numpy().copy()            # accumulators at the start of the timed region
+    retry_before = retry_ctr.cpu().numpy().copy()
 
     # ---- timed region ----
     if world > 1:
@@ -170,9 +242,9 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for k in range(args.steps):
-        out = step()
-    lanes.drain()                           # verify (and publish: all-gather at N > 1) the batches still in flight
-    t_enq = time.perf_counter() - t0        # host time in the loop (it waits for the batch `lanes` steps back)
+        runner.step()
+    rows = runner.finish()                  # verify and publish (all-gather at N > 1) the batches still in flight
+    t_enq = time.perf_counter() - t0
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -181,91 +253,259 @@ def main():
         t = torch.tensor([dt], dtype=torch.float64, device="cpu" if args.share_gpu else device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+    sp = spans.cpu().numpy()
+    retry_after = retry_ctr.cpu().numpy()
+    assert rows.shape == ((n_rec if world > 1 else len(mine)), nb * pipeline.RESULT_COLS)
+    finite_frac = float(torch.isfinite(rows).double().mean().item())
+
+    # ---- secondary legs (outside the headline's timed region) ----
+    extras = {}
+    if not args.no_extras and uniform:
+        if args.features_steps > 0:
+            extras["features_pass"] = features_leg(args, ctx, device, mine, shards, n_rec, rank, world, nb)
+        if rank == 0:
+            extras["pcie_inclusive"] = pcie_leg(ctx, device, eeg[nb - 2], aud[nb - 2], wpr)
 
     if rank == 0:
-        total_windows = world * n_win * args.steps
-        value = total_windows / dt
-        dom = DOM
-        sp = spans.cpu().numpy()
+        value = total_pairs * args.steps / dt
         launches = int(sp[:, 3].sum() - sp_before[:, 3].sum())
-        assert launches == args.steps, f"probe saw {launches} launches of the dominant kernel, expected {args.steps}"
+        exp = args.steps * nb
+        assert launches == exp, f"probe saw {launches} launches of the dominant kernel, expected {exp}"
         kernel_ms = float(sp[:, 2].sum() - sp_before[:, 2].sum()) / launches / 100e6 * 1e3   # timed region only
         kernel_ms_all = float(sp[:, 2].sum()) / int(sp[:, 3].sum()) / 100e6 * 1e3            # every launch of the process
-        achieved = ALG_BYTES[dom] * n_win / (kernel_ms * 1e-3) / 1e9
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tpath):
+        achieved = ALG_BYTES[DOM] * n_win_batch / (kernel_ms * 1e-3) / 1e9
+
+        def prof(name):
+            path = os.path.join(ROOT, "profiles", name)
             try:
-                traffic = json.load(open(tpath)).get(dom)
+                return json.load(open(path))
             except Exception:
-                traffic = None
+                return None
+        traffic = (prof("traffic.json") or {}).get(DOM)
         line = {
             "metric": "windows/sec end-to-end (dist->Rips H0/H1->Wasserstein), 47-ch EEG",
-            "value": value, "unit": "windows/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "value": value, "unit": "windows/s", "n_gpus": world, "steps": args.steps, "warmup": max(1, args.warmup),
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "strong" if args.workload == "corpus" else "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"configs[1]: {n_win} EEG windows (47x250 f64) x 1 band ({args.band}) per GPU, "
-                                   f"+ {n_win} audio windows (250 f64); corr->dist->Rips H0/H1 (EEG 47 pts, audio "
-                                   f"Takens dim 3 sub 2), Wasserstein H0+H1, H1 features, per-recording "
-                                   f"({wpr} windows) reductions" + ("; one all-gather of result rows" if world > 1 else ""),
-                       "windows_per_gpu": n_win, "thresh": 2.0, "parallelism": f"recordings sharded x{world}",
+            "config": {"workload": f"{cfg_label}: {n_rec} recordings x {nb} bands x {wpr if uniform else '15 (last: 5)'} "
+                                   f"selected windows = {total_pairs} (EEG 47x250 f64, audio 250 f64) window pairs per "
+                                   f"pass, the whole job; per pair corr->dist->Rips H0/H1 (EEG 47 pts), tau per "
+                                   f"recording-band, Takens dim 3 sub 2 + Rips (audio, 23..123 pts over the bands), "
+                                   f"Wasserstein H0+H1, features, per-recording reductions; one all-gather of the "
+                                   f"({n_rec}, {nb}x48) rows per pass",
+                       "windows_per_pass": total_pairs, "windows_per_gpu_per_pass": int(n_win_batch * nb),
+                       "input_bytes_per_gpu": int(sum(e.numel() for e in eeg) * 8 + sum(a.numel() for a in aud) * 8),
+                       "band_batches_per_pass": nb, "windows_per_band_batch": int(n_win_batch), "thresh": 2.0,
+                       "parallelism": f"recordings dealt over {world} rank(s), one all-gather per pass",
                        "batches_in_flight": lanes.depth, "hip_graph": lanes.graph,
-                       "deferred_retries": lanes.defer, "batches_repaired": lanes.repairs,
-                       "first_pass_class_bits": {"eeg": 64 if not os.environ.get("TDA_CLASS_WORDS") else None, "audio": 32}},
-            "stage_ms": {s: round(v, 4) for s, v in stage_ms.items()},       # eager warm-up steps, overlapping lanes
-            "host_loop_ms_per_step": round(t_enq / args.steps * 1e3, 4),   # includes the wait for the batch `lanes` steps back
+                       "first_pass_class_bits": {"eeg": 64 * cw_dm, "audio": 32 * cw_cloud if cw_cloud == 1 else 64},
+                       "windows_repaired": {"eeg": int(retry_after[0] - retry_before[0]),
+                                            "audio": int(retry_after[1] - retry_before[1]),
+                                            "note": "windows redone by the widening passes inside the timed steps"},
+                       "result_rows_finite_frac": round(finite_frac, 6),
+                       "data_generation_s": round(t_gen, 2)},
+            "stage_ms": {s: round(v, 4) for s, v in stage_ms.items()},     # one eager pass, band batches one at a time
+            "host_loop_ms_per_step": round(t_enq / args.steps * 1e3, 4),
             "roofline": {"bound": "hbm", "kernel": "rips_cloud_kernel<512, 1, unsigned int> (stage rips_audio)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel_ms": round(kernel_ms, 4),
-                         "event_ms": round(event_ms, 4), "kernel_ms_all_launches": round(kernel_ms_all, 4),
+                         "event_ms": round(float(np.mean(event_ms)), 4), "event_ms_per_band": [round(x, 4) for x in event_ms],
+                         "kernel_ms_all_launches": round(kernel_ms_all, 4),
                          "launches_probed": int(sp[:, 3].sum()),
-                         "alg_bytes_per_launch": ALG_BYTES[dom] * n_win,
-                         "note": "irregular integer work in LDS/registers (LDS latency/issue bound); the HBM fraction is "
-                                 "small by construction.  kernel_ms: average over every launch of the timed region of "
-                                 "(first workgroup start .. last workgroup end), stamped by the kernel itself (100 MHz wall "
-                                 "clock) -- the interval rocprofv3 --kernel-trace reports; `achieved` uses it.  "
-                                 "kernel_ms_all_launches: the same over every launch of this kernel in the process (warm-up and "
-                                 "capture steps included), the population rocprofv3 --stats averages.  event_ms: HIP "
-                                 "events around the same launch on its stream in the eager warm-up steps; with several "
-                                 "batches in flight it includes the time the grid waits for CU slots held by the others"},
+                         "alg_bytes_per_launch": ALG_BYTES[DOM] * n_win_batch,
+                         "note": "irregular integer work in LDS/registers: the resource that binds it is LDS latency / "
+                                 "issue (see roofline_lds), so the HBM fraction is small by construction.  kernel_ms: "
+                                 "average over every launch of the timed region of (first workgroup start .. last "
+                                 "workgroup end), stamped by the kernel itself (100 MHz wall clock) -- the interval "
+                                 "rocprofv3 --kernel-trace reports; `achieved` uses it.  event_ms: HIP events around the "
+                                 "same launch on its stream, band batches alone (eager warm-up pass)"},
+            "roofline_lds": prof("r02_lds_roofline.json"),
         }
-        cd_ms = min(hbm_ms)
-        line["roofline_hbm_kernel"] = {
-            "kernel": "corr_dist_kernel<3, true> (stage corr_dist)", "bound": "hbm", "achieved": ALG_BYTES["corr_dist"] * n_win / (cd_ms * 1e-3) / 1e9,
-            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ALG_BYTES["corr_dist"] * n_win / (cd_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-            "event_ms": round(cd_ms, 4), "alg_bytes_per_launch": ALG_BYTES["corr_dist"] * n_win,
-            "traffic": (json.load(open(tpath)).get("corr_dist") if os.path.exists(tpath) else None),
-            "note": "secondary: the one HBM-streaming kernel of the step (5-8 % of its GPU time); HIP events around the launch in "
-                    "warm-up steps that run alone (best of 3); 710 windows fill the 256 CUs 0.9 times, the kernel reaches "
-                    "2.5 TB/s on 11,360 windows (DESIGN.md 3.1)"}
+        line.update(extras)
         if not args.no_cpu:
-            line["cpu_baseline"] = cpu_baseline(eeg, aud, seg_off, args.cpu_seconds)
+            line["cpu_baseline"] = cpu_baseline(eeg, aud, wpr if uniform else 15, args.cpu_seconds)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    return 0
 
 
-def cpu_baseline(eeg, aud, seg_off, budget_s):
-    """CPU oracle (C restatement of the ripser-class algorithm + persim's assignment), 1 core,
-    timed on whole recordings of the SAME batch until ~budget_s seconds are spent."""
-    from oracle import pipeline_ref      # the ONLY use of oracle/ here: the timed CPU port
-    done = 0
+def features_leg(args, ctx, device, mine, shards, n_rec, rank, world, nb):
+    """BASELINE.json configs[2]: EEG Rips + features on the min-equalised windows of every recording-band
+    (v2:79-82,519-527: 39), (n_rec, 220) matrix all-gathered once per pass."""
+    import torch
+    import torch.distributed as dist
+    from tda_eeg_audio_amd import pipeline, synth
+    from tda_eeg_audio_amd import dist as tdist
+    fw = args.features_windows
+    eeg = synth.corpus_eeg_dev(mine, fw, nb, device, seed=4343)
+    n_win = eeg[0].shape[0]
+    seg_off = np.arange(0, n_win + 1, fw, dtype=np.int32)
+    ws = pipeline.Workspace(n_win, seg_off, device)
+    block = torch.empty((len(mine), nb, 44), dtype=torch.float64, device=device)
+
+    def one_pass():
+        for b in range(nb):
+            block[:, b].copy_(pipeline.run_features_step(eeg[b], ws, ctx=ctx))
+        flat = block.view(len(mine), nb * 44)
+        return tdist.all_gather_rows(flat, mine, shards, n_rec) if world > 1 else flat
+    X = one_pass()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
     t0 = time.perf_counter()
-    s = 0
-    n_seg = len(seg_off) - 1
-    while True:
-        a, b = int(seg_off[s % n_seg]), int(seg_off[s % n_seg + 1])
-        pipeline_ref.reference_step_cpu(eeg[a:b], aud[a:b], np.array([0, b - a]))
-        done += b - a
-        s += 1
-        el = time.perf_counter() - t0
-        if el >= budget_s:
-            break
-    return {"value": done / el, "unit": "windows/s", "cores": 1, "kind": "port",
-            "sample": f"{done} windows ({s} recordings, cycling through the batch of {int(seg_off[-1])}), {el:.1f} s, oracle/tda_oracle.c "
-                      f"(gcc -O2), same end-to-end unit"}
+    for _ in range(args.features_steps):
+        X = one_pass()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cpu" if args.share_gpu else device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    bad = int((ws.eeg.status != 0).sum().item())
+    total = n_rec * nb * fw
+    del eeg, ws
+    torch.cuda.empty_cache()
+    return {"workload": f"configs[2]: {n_rec} recordings x {nb} bands x {fw} windows = {total} EEG windows -> "
+                        f"({n_rec}, {nb * 44}) feature matrix, one all-gather per pass",
+            "value": total * args.features_steps / dt, "unit": "windows/s", "steps": args.features_steps,
+            "ms_per_step": dt / args.features_steps * 1e3, "matrix_shape": list(X.shape),
+            "matrix_finite": bool(torch.isfinite(X).all().item()), "windows_bad_status": bad}
+
+
+def pcie_leg(ctx, device, eeg_b, aud_b, wpr, n_rec=256):
+    """PCIe-inclusive rate (never `value`): pinned host windows -> HBM -> the same step -> result rows back to the
+    host, copies and kernels on one stream; a bounded sample of one band's batch."""
+    import torch
+    from tda_eeg_audio_amd import pipeline
+    n_win = min(eeg_b.shape[0], n_rec * wpr)
+    n_win -= n_win % wpr
+    eeg_h = eeg_b[:n_win].cpu().pin_memory()
+    aud_h = aud_b[:n_win].cpu().pin_memory()
+    eeg_d = torch.empty_like(eeg_h, device=device)
+    aud_d = torch.empty_like(aud_h, device=device)
+    seg_off = np.arange(0, n_win + 1, wpr, dtype=np.int32)
+    ws = pipeline.Workspace(n_win, seg_off, device)
+    out_h = torch.empty((len(seg_off) - 1, pipeline.RESULT_COLS), dtype=torch.float64).pin_memory()
+
+    def step():
+        eeg_d.copy_(eeg_h, non_blocking=True)
+        aud_d.copy_(aud_h, non_blocking=True)
+        out_h.copy_(pipeline.run_step(eeg_d, aud_d, ws, ctx=ctx), non_blocking=True)
+    for _ in range(2):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    K = 8
+    for _ in range(K):
+        step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / K
+    nbytes = eeg_h.numel() * 8 + aud_h.numel() * 8
+    return {"value": n_win / dt, "unit": "windows/s", "stage": "h2d + step + d2h, one stream, pinned host buffers",
+            "sample": f"{n_win} window pairs of one band ({nbytes / 1e6:.0f} MB uploaded per step)",
+            "h2d_GBps": nbytes / dt / 1e9, "ms_per_step": dt * 1e3}
+
+
+# ------------------------------------------------------------------------------------------------------------
+# cpu_baseline: the CPU oracle on a bounded sample of the same workload, in a child process that never touches a GPU
+# ------------------------------------------------------------------------------------------------------------
+def cpu_baseline(eeg, aud, wpr, budget_s, n_rec=8):
+    """Sample = the first recordings of this rank's share, all five bands.  The child process (this file with
+    --cpu-worker) rebuilds oracle/tda_oracle.c with -O3 -march=native on THIS host and times orc_segment_step
+    (one (recording, band) group end to end, in C): first on one core, then on all the cores it may use with a
+    process pool over the groups (the reference's joblib processes, v2:569-572)."""
+    import tempfile
+    n = min(n_rec, eeg[0].shape[0] // wpr) * wpr
+    tmpdir = "/dev/shm" if os.path.isdir("/dev/shm") else None
+    with tempfile.TemporaryDirectory(dir=tmpdir) as td:
+        path = os.path.join(td, "sample.npz")
+        np.savez(path, eeg=np.stack([e[:n].cpu().numpy() for e in eeg]), aud=np.stack([a[:n].cpu().numpy() for a in aud]),
+                 wpr=wpr, budget=budget_s)
+        env = dict(os.environ)
+        for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+            env.pop(k, None)
+        out = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-worker", path], env=env,
+                             capture_output=True, text=True, timeout=max(300.0, 20 * budget_s))
+    if out.returncode != 0:
+        return {"error": out.stderr[-500:]}
+    return json.loads(out.stdout.strip().splitlines()[-1])
+
+
+def _cpu_group(job):
+    from oracle import port
+    e, a = job
+    t0 = time.perf_counter()
+    port.segment_step(e, a)
+    return time.perf_counter() - t0
+
+
+def _cpu_init():
+    from oracle import port
+    port.use_native()
+
+
+def cpu_worker(path):
+    import multiprocessing as mp
+    from oracle import port                 # the ONLY use of oracle/ in this file: the timed CPU port
+    flags = port.use_native()
+    z = np.load(path)
+    eeg, aud, wpr, budget = z["eeg"], z["aud"], int(z["wpr"]), float(z["budget"])
+    nb, n = eeg.shape[0], eeg.shape[1]
+    groups = [(eeg[b, r:r + wpr], aud[b, r:r + wpr]) for r in range(0, n, wpr) for b in range(nb)]   # recording-major
+    cpu_model = "unknown"
+    phys = set()
+    try:
+        pid = cid = None
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                cpu_model = ln.split(":", 1)[1].strip()
+            elif ln.startswith("physical id"):
+                pid = ln.split(":")[1].strip()
+            elif ln.startswith("core id"):
+                cid = ln.split(":")[1].strip()
+                phys.add((pid, cid))
+    except OSError:
+        pass
+    avail = len(os.sched_getaffinity(0))
+    workers = max(1, min(avail, int(os.environ.get("TDA_CPU_WORKERS", "16"))))
+    # ---- one core: >= 5 samples, each one recording (nb groups) ----
+    _cpu_group(groups[0])                                            # warm
+    samples1, t_spent, i = [], 0.0, 0
+    while len(samples1) < 5 or (t_spent < 0.4 * budget and len(samples1) < 50):
+        t = sum(_cpu_group(groups[(i * nb + j) % len(groups)]) for j in range(nb))
+        samples1.append(nb * wpr / t)
+        t_spent += t
+        i += 1
+    # ---- all cores: a pool over the groups, >= 5 samples of `workers` x 2 groups each ----
+    samples_n = []
+    with mp.get_context("fork").Pool(workers, initializer=_cpu_init) as pool:
+        batch = [groups[j % len(groups)] for j in range(2 * workers)]
+        pool.map(_cpu_group, batch)                                      # warm
+        t_spent = 0.0
+        while len(samples_n) < 5 or (t_spent < 0.5 * budget and len(samples_n) < 50):
+            t0 = time.perf_counter()
+            pool.map(_cpu_group, batch, chunksize=1)
+            t = time.perf_counter() - t0
+            samples_n.append(len(batch) * wpr / t)
+            t_spent += t
+    v1, vn = float(np.median(samples1)), float(np.median(samples_n))
+    print(json.dumps({
+        "value": v1, "unit": "windows/s", "cores": 1, "kind": "port",
+        "value_all_cores": vn, "cores_all": workers, "cores_total": os.cpu_count(), "cores_physical": len(phys) or None,
+        "cores_available": avail, "cpu_model": cpu_model, "build": flags,
+        "sample": f"oracle/tda_oracle.c::orc_segment_step ({flags}), the same end-to-end unit on whole (recording, band) "
+                  f"groups of {wpr} window pairs drawn from {n // wpr} recordings x {nb} bands of this workload; 1 core: "
+                  f"median of {len(samples1)} samples of {nb} groups; all cores: process pool of {workers} over the "
+                  f"groups (v2:569-572 joblib processes), median of {len(samples_n)} samples of {2 * workers} groups; "
+                  f"RESTATED baseline (ripser/persim are not installable offline)",
+        "samples_1core": [round(x, 1) for x in samples1[:10]], "samples_all_cores": [round(x, 1) for x in samples_n[:10]]}))
+    return 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main() or 0)

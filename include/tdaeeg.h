@@ -79,6 +79,11 @@ tda_status tda_set_class_words(tda_ctx* ctx, int words_dm, int words_cloud);
 #define TDA_RETRY_FIRST_PASS 1
 #define TDA_RETRY_ONLY       2
 tda_status tda_set_retry_policy(tda_ctx* ctx, int policy);
+/* Optional accounting of the widening passes: dev_counters = DEVICE u64[2] (or NULL to stop).  Every window a
+ * widening pass redoes adds one to [0] (distance-matrix input, tda_rips_dm_batch) or [1] (point clouds,
+ * tda_takens_rips_batch / tda_cloud_rips_batch); a window that climbs two rungs of the ladder counts twice.
+ * The reference has no counterpart (ripser's columns grow on the heap); bench.py reports it as windows_repaired. */
+tda_status tda_set_retry_counter(tda_ctx* ctx, void* dev_counters);
 
 /* ---- corr -> distance ------------------------------------------------------
  * replaces compute_correlation_matrix + correlation_to_distance(method="euclidean")

@@ -24,12 +24,17 @@ def reference_step_cpu(eeg_win, audio_win, seg_off, max_lag=125):
             _, d = port.corr_dist(eeg_win[w])
             e = port.rips_dm(d)
             (au, P) = port.audio_persistence(audio_win[w], tau)
+            f0.append(port.features(e[0])); f1.append(port.features(e[1]))
+            if P < 3:                      # cmp:90-91: the window takes no part in the distances
+                continue
             w0.append(port.wasserstein(_clean(e[0]), _clean(au[0])))
             w1.append(port.wasserstein(_clean(e[1]), _clean(au[1])))
-            f0.append(port.features(e[0])); f1.append(port.features(e[1]))
             port.features(au[1])
         f0 = np.array(f0); f1 = np.array(f1)
-        res[s, 0] = np.nanmean(w0); res[s, 1] = np.nanmean(w1); res[s, 2] = tau; res[s, 3] = b - a
+        # cmp:101-102 drops the band when no window survived; here its two distances are NaN
+        res[s, 0] = np.nanmean(w0) if w0 else np.nan
+        res[s, 1] = np.nanmean(w1) if w1 else np.nan
+        res[s, 2] = tau; res[s, 3] = b - a
         for f in range(11):
             res[s, 4 + 4 * f: 8 + 4 * f] = [f0[:, f].mean(), f0[:, f].std(), f1[:, f].mean(), f1[:, f].std()]
     return res

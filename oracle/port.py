@@ -12,6 +12,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.path.join(_HERE, "libtda_oracle.so")
+_SO_NATIVE = os.path.join(_HERE, "libtda_oracle_native.so")
 _lib = None
 
 c_dp = C.POINTER(C.c_double)
@@ -54,8 +55,31 @@ def lib():
         L.orc_wasserstein.restype = C.c_double
         L.orc_eeg_prepare.argtypes = [c_dp, C.c_int, C.c_int, c_fp]
         L.orc_eeg_prepare.restype = None
+        _bind_segment(L)
         _lib = L
     return _lib
+
+
+def _bind_segment(L):
+    L.orc_segment_step.argtypes = [c_dp, c_dp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, c_dp]
+    L.orc_segment_step.restype = C.c_int
+
+
+def use_native():
+    """Timing leg only (bench.py cpu_baseline): rebuild the SAME source with -O3 -march=native on this
+    host and bind it; falls back to the portable build when the compiler is missing.  Returns the flags."""
+    global _lib
+    try:
+        subprocess.check_call(["make", "-C", _HERE, "-s", "native"])
+        L = C.CDLL(_SO_NATIVE)
+        _bind_segment(L)
+        lib()                       # the portable one stays bound for everything else
+        _lib.orc_segment_step = L.orc_segment_step
+        _lib._native = L
+        return "gcc -O3 -march=native"
+    except Exception:
+        lib()
+        return "gcc -O3"
 
 
 def _d(a):
@@ -178,3 +202,13 @@ def features(dgm):
 def wasserstein(a, b):
     a = _d(np.asarray(a).reshape(-1, 2)); b = _d(np.asarray(b).reshape(-1, 2))
     return float(lib().orc_wasserstein(_p(a, c_dp), a.shape[0], _p(b, c_dp), b.shape[0]))
+
+
+def segment_step(eeg_win, audio_win, max_lag=125, thresh=2.0):
+    """One (recording, band) group end to end in C (orc_segment_step): the 48-value result row."""
+    e = _d(eeg_win); a = _d(audio_win)
+    n_win, n_ch, n_t = e.shape
+    row = np.empty(48)
+    st = lib().orc_segment_step(_p(e, c_dp), _p(a, c_dp), n_win, n_ch, n_t, int(max_lag), float(thresh), _p(row, c_dp))
+    assert st == 0
+    return row

@@ -701,3 +701,84 @@ ORC_EXPORT int orc_rips_dm_batch(const double* dist, int n_win, int n, double th
                           h1 + (size_t)w * h1_cap * 2, h1_cap, n_h1 + w);
     return st;
 }
+
+/* ------------------------------------------------------------------------- */
+/* the end-to-end unit of one (recording, band) group, all in C               */
+/* ------------------------------------------------------------------------- */
+/* The hot loop of process_recording (scripts/tda_eeg_audio_comparison.py:83-118) for the
+ * n_win selected windows of one band, fed from the EEG windows instead of the stored
+ * matrices (corr -> dist of nb2:198-207 in front), plus the mean/std aggregation of
+ * process_file_features (scripts/tda_eeg_classification_v2.py:429-436) over the same windows:
+ *   tau from the first window (cmp:83); per window Takens -> skip if < 3 points (cmp:90-91)
+ *   -> Rips(audio), Rips(EEG), Wasserstein H0 and H1 (cmp:95-96), features of both H1
+ *   diagrams (cmp:98-99) and of the EEG H0 diagram (v2:415); np.nanmean of the distances
+ *   (cmp:117-118; NaN when no window survived, where the reference drops the band, cmp:101-102).
+ * row (48): [W_H0, W_H1, tau, n_win, 44 x {h0 mean, h0 std, h1 mean, h1 std} per feature].
+ * This is what bench.py's cpu_baseline leg times (no Python between the stages). */
+static void clean_rows(const float* rows, int k, double* out, int* m_out)
+{
+    int m = 0;
+    for (int i = 0; i < k; ++i)
+        if (isfinite(rows[2 * i]) && isfinite(rows[2 * i + 1])) { out[2 * m] = rows[2 * i]; out[2 * m + 1] = rows[2 * i + 1]; ++m; }
+    if (m == 0) { out[0] = 0.0; out[1] = 0.0; m = 1; }     /* utils:186-187 */
+    *m_out = m;
+}
+
+static double np_nanmean(const double* x, int n)
+{
+    double* t = (double*)malloc(sizeof(double) * (size_t)(n > 0 ? n : 1));
+    int c = 0;
+    for (int i = 0; i < n; ++i) if (x[i] == x[i]) t[c++] = x[i];
+    double r = c ? np_pairwise_sum(t, c) / (double)c : NAN;
+    free(t);
+    return r;
+}
+
+ORC_EXPORT int orc_segment_step(const double* eeg, const double* aud, int n_win, int n_ch, int n_t,
+                                int max_lag, double thresh, double* row)
+{
+    const int e_cap1 = n_ch * (n_ch - 1) / 2 + 1, a_cap0 = 260, a_cap1 = 130 * 129 / 2;
+    float* e0 = (float*)malloc(sizeof(float) * 2 * (size_t)(n_ch + 1));
+    float* e1 = (float*)malloc(sizeof(float) * 2 * (size_t)e_cap1);
+    float* a0 = (float*)malloc(sizeof(float) * 2 * (size_t)a_cap0);
+    float* a1 = (float*)malloc(sizeof(float) * 2 * (size_t)a_cap1);
+    double* dist = (double*)malloc(sizeof(double) * (size_t)n_ch * n_ch);
+    double* da = (double*)malloc(sizeof(double) * 2 * (size_t)(e_cap1 > a_cap1 ? e_cap1 : a_cap1));
+    double* db = (double*)malloc(sizeof(double) * 2 * (size_t)(e_cap1 > a_cap1 ? e_cap1 : a_cap1));
+    double* w0 = (double*)malloc(sizeof(double) * (size_t)n_win), *w1 = (double*)malloc(sizeof(double) * (size_t)n_win);
+    double* f0 = (double*)malloc(sizeof(double) * 11 * (size_t)n_win), *f1 = (double*)malloc(sizeof(double) * 11 * (size_t)n_win);
+    double* col = (double*)malloc(sizeof(double) * (size_t)n_win);
+    int st = 0, nw = 0;
+    const int tau = orc_compute_tau(aud, n_t, max_lag);
+    for (int w = 0; w < n_win; ++w) {
+        int k0, k1, j0, j1, P, m, n;
+        orc_corr_dist(eeg + (size_t)w * n_ch * n_t, n_ch, n_t, 0, dist);
+        st |= orc_rips_dm(dist, n_ch, thresh, 1, e0, n_ch + 1, &k0, e1, e_cap1, &k1);
+        for (int i = 0; i < k0; ++i) { da[2 * i] = e0[2 * i]; da[2 * i + 1] = e0[2 * i + 1]; }
+        orc_features(da, k0, f0 + 11 * (size_t)w);
+        for (int i = 0; i < k1; ++i) { da[2 * i] = e1[2 * i]; da[2 * i + 1] = e1[2 * i + 1]; }
+        orc_features(da, k1, f1 + 11 * (size_t)w);
+        st |= orc_audio_persistence(aud + (size_t)w * n_t, n_t, 3, tau, 2, thresh, a0, a_cap0, &j0, a1, a_cap1, &j1, &P);
+        if (P < 3) continue;                                     /* cmp:90-91 */
+        clean_rows(e0, k0, da, &m); clean_rows(a0, j0, db, &n);
+        w0[nw] = orc_wasserstein(da, m, db, n);
+        clean_rows(e1, k1, da, &m); clean_rows(a1, j1, db, &n);
+        w1[nw] = orc_wasserstein(da, m, db, n);
+        double fa[11];
+        for (int i = 0; i < j1; ++i) { db[2 * i] = a1[2 * i]; db[2 * i + 1] = a1[2 * i + 1]; }
+        orc_features(db, j1, fa);                                /* cmp:98 (feeds the Spearman series) */
+        ++nw;
+    }
+    row[0] = np_nanmean(w0, nw); row[1] = np_nanmean(w1, nw); row[2] = (double)tau; row[3] = (double)n_win;
+    for (int f = 0; f < 11; ++f)
+        for (int h = 0; h < 2; ++h) {
+            const double* ff = h ? f1 : f0;
+            for (int w = 0; w < n_win; ++w) col[w] = ff[11 * (size_t)w + f];
+            const double mean = np_pairwise_sum(col, n_win) / (double)n_win;
+            for (int w = 0; w < n_win; ++w) { const double z = col[w] - mean; col[w] = z * z; }
+            row[4 + 4 * f + 2 * h] = mean;
+            row[5 + 4 * f + 2 * h] = sqrt(np_pairwise_sum(col, n_win) / (double)n_win);
+        }
+    free(e0); free(e1); free(a0); free(a1); free(dist); free(da); free(db); free(w0); free(w1); free(f0); free(f1); free(col);
+    return st;
+}

@@ -60,6 +60,7 @@ SYMBOLS = {
     "tda_tau_segments_dev": (_I, [c_vp, c_vp, c_vp, _I, _I, _I, c_vp, c_vp, c_vp]),
     "tda_recording_rows_dev": (_I, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, _I, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "tda_set_retry_policy": (_I, [c_vp, _I]),
+    "tda_set_retry_counter": (_I, [c_vp, c_vp]),
     "tda_tau_batch": (_I, [c_vp, c_vp, _I, _I, _I, c_vp]),
     "tda_features_batch_dev": (_I, [c_vp, c_vp, c_vp, _I, _I, c_vp, c_vp]),
     "tda_features_batch": (_I, [c_vp, c_vp, c_vp, _I, _I, c_vp]),
@@ -142,6 +143,10 @@ class Context:
 
     def set_retry_policy(self, policy):
         self.check(self.lib.tda_set_retry_policy(self.h, int(policy)))
+
+    def set_retry_counter(self, dev_ptr):
+        """dev_ptr: device address of a zeroed u64[2] (or None): windows redone by the widening passes."""
+        self.check(self.lib.tda_set_retry_counter(self.h, c_vp(dev_ptr) if dev_ptr else None))
 
     # ---- one-shot kernel probe (bench.py roofline): HIP events around ONE first-pass kernel ----
     PROBES = {"rips_audio": 1, "rips_eeg": 2, "corr_dist": 3}

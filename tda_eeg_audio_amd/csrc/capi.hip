@@ -59,6 +59,13 @@ tda_status tda_set_class_words(tda_ctx* ctx, int words_dm, int words_cloud)
     return TDA_OK;
 }
 
+tda_status tda_set_retry_counter(tda_ctx* ctx, void* dev_counters)
+{
+    if (!ctx) return TDA_ERR_INVALID;
+    ctx->retry_ctr = (unsigned long long*)dev_counters;
+    return TDA_OK;
+}
+
 tda_status tda_set_retry_policy(tda_ctx* ctx, int policy)
 {
     if (!ctx) return TDA_ERR_INVALID;

@@ -14,6 +14,7 @@ struct tda_ctx {
     int words_dm = 2;       // H1 class capacity (x64) for distance-matrix input
     int words_cloud = 1;    // ... for point clouds
     int retry_policy = 0;   // TDA_RETRY_*
+    unsigned long long* retry_ctr = nullptr;   // tda_set_retry_counter: device u64[2]
     // host-API staging workspace (grown on demand, only by the host-pointer twins)
     void* ws = nullptr;
     size_t ws_bytes = 0;

@@ -252,11 +252,26 @@ recording_rows_kernel(const double* __restrict__ w0, const double* __restrict__ 
         row[4 + f * 4 + h * 2] = mean;
         row[4 + f * 4 + h * 2 + 1] = sd;
     } else if (lane < 2 * TDA_N_FEATURES + 2) {
+        // cmp:90-91: a window whose Takens cloud has fewer than 3 points (or none at all) never reaches the
+        // distances; np.nanmean then runs over the list of the windows that did (cmp:117-118).  No window left:
+        // the reference drops the band (cmp:101-102), here the two distances are NaN.
         const double* x = lane == 2 * TDA_N_FEATURES ? w0 : w1;
-        int cnt = 0;
-        for (int i = s0; i < s1; ++i) cnt += (x[i] == x[i]) ? 1 : 0;
-        auto val = [=](int i) { const double v = x[s0 + i]; return v == v ? v : 0.0; };
-        const double sum = np_pairwise_fn(val, 0, n);
+        const int skip = TDA_WIN_DEGENERATE | TDA_WIN_TOO_LARGE;
+        int m = 0, cnt = 0;
+        for (int i = s0; i < s1; ++i) {
+            if (status_b && (status_b[i] & skip)) continue;
+            ++m;
+            cnt += (x[i] == x[i]) ? 1 : 0;
+        }
+        // the j-th surviving window (the survivors keep their order, so the pairwise tree is numpy's)
+        auto val = [=](int j) {
+            int i = s0;
+            if (status_b) { for (int seen = -1;; ++i) { if (!(status_b[i] & skip) && ++seen == j) break; } }
+            else i = s0 + j;
+            const double v = x[i];
+            return v == v ? v : 0.0;
+        };
+        const double sum = np_pairwise_fn(val, 0, m);
         row[lane - 2 * TDA_N_FEATURES] = cnt > 0 ? sum / (double)cnt : __longlong_as_double(0x7ff8000000000000ll);
     } else if (lane == 2 * TDA_N_FEATURES + 2) {
         row[2] = (double)tau_seg[seg];

@@ -1328,11 +1328,12 @@ __device__ __noinline__ void row_maxima(const u32* key32, u32* vmax, int P)
 template <int NT, int NVW, int W, typename WT>
 __global__ void __launch_bounds__(NT, W <= 2 ? 4 : 1)
 rips_dm_kernel(const double* __restrict__ dm, int n_win, int n, float thresh, int symmetrise, RipsLayout L,
-               RipsOut out, int retry_only)
+               RipsOut out, int retry_only, unsigned long long* __restrict__ retry_ctr)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     for (int win = blockIdx.x; win < n_win; win += gridDim.x) {
         if (retry_only && !(out.status[win] & TDA_WIN_CLASS_OVERFLOW)) continue;   // workgroup-uniform
+        if (retry_only && retry_ctr && threadIdx.x == 0) atomicAdd(retry_ctr, 1ull);
         rips_dm_window<NT, NVW, W, WT>(smem, win, dm, n, thresh, symmetrise, L, out);
         __syncthreads();
     }
@@ -1466,7 +1467,7 @@ __global__ void __launch_bounds__(NT, CLOUD_WAVES)
 rips_cloud_kernel(const double* __restrict__ src, const int* __restrict__ tau_or_npts, int n_win,
                   int n_t_or_pcap, int dim, int subsample, int mode, int normalise, float thresh,
                   RipsLayout L, int p_max, int* __restrict__ n_points, RipsOut out, int retry_only,
-                  unsigned long long* __restrict__ span)
+                  unsigned long long* __restrict__ span, unsigned long long* __restrict__ retry_ctr)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     // armed probe only (100 MHz wall clock): span[0] = start of workgroup 0 of this launch, span[1] = workgroups
@@ -1477,6 +1478,7 @@ rips_cloud_kernel(const double* __restrict__ src, const int* __restrict__ tau_or
         atomicExch(&span[0], wall_clock64());
     for (int win = blockIdx.x; win < n_win; win += gridDim.x) {
         if (retry_only && !(out.status[win] & TDA_WIN_CLASS_OVERFLOW)) continue;   // workgroup-uniform
+        if (retry_only && retry_ctr && threadIdx.x == 0) atomicAdd(retry_ctr + 1, 1ull);
         rips_cloud_window<NT, W, WT>(smem, win, src, tau_or_npts, n_t_or_pcap, dim, subsample, mode, normalise,
                                      thresh, L, p_max, n_points, out);
         __syncthreads();
@@ -1572,12 +1574,12 @@ static tda_status launch_dm_t(tda_ctx* ctx, const double* dm, int n_win, int n, 
                                          hipFuncAttributeMaxDynamicSharedMemorySize, L.total));
     // retry passes walk the status array on a small strided grid; the widest variant (240 VGPRs, > 80 KB LDS)
     // needs a nearly empty CU per workgroup, so it asks for few of them
-    const int rgrid = W >= 8 ? 16 : 64;
+    const int rgrid = W >= 8 ? 32 : 256;
     const int grid = retry_only ? (n_win < rgrid ? n_win : rgrid) : n_win;
     {
         ProbeScope probe(ctx, retry_only ? -1 : TDA_PROBE_RIPS_DM, st);
         hipLaunchKernelGGL(kern, dim3(grid), dim3(NT), L.total, st, dm, n_win, n, thresh, symmetrise, L, out,
-                           retry_only);
+                           retry_only, ctx->retry_ctr);
     }
     TDA_HIP(ctx, hipGetLastError());
     return TDA_OK;
@@ -1640,11 +1642,12 @@ static tda_status launch_cloud_t(tda_ctx* ctx, const double* src, const int* aux
     if (L.total > 48 * 1024)
         TDA_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, L.total));
-    const int grid = retry_only ? (n_win < 64 ? n_win : 64) : n_win;
+    const int grid = retry_only ? (n_win < 256 ? n_win : 256) : n_win;
     {
         ProbeScope probe(ctx, retry_only ? -1 : TDA_PROBE_RIPS_CLOUD, st);
         hipLaunchKernelGGL(kern, dim3(grid), dim3(NT), L.total, st, src, aux, n_win, n_t_or_pcap, dim, subsample, mode,
-                           normalise, thresh, L, p_max, n_points, out, retry_only, probe.on ? probe.span : nullptr);
+                           normalise, thresh, L, p_max, n_points, out, retry_only, probe.on ? probe.span : nullptr,
+                           ctx->retry_ctr);
     }
     TDA_HIP(ctx, hipGetLastError());
     return TDA_OK;

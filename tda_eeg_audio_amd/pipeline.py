@@ -180,14 +180,14 @@ class Lanes:
             b.value = b.post(ws.result) if b.post is not None else ws.result
         b.done = True
 
-    def submit(self, eeg_win, audio_win, ctx=None, max_lag=125, timers=None, post=None, sync_inputs=True):
+    def submit(self, eeg_win, audio_win, ctx=None, max_lag=125, timers=None, post=None, sync_inputs=True, lane=None):
         """Enqueue one step on the next lane and return its Batch handle.  The batch that used the lane before
         is finalized first (see class docstring).  `post(result)` runs on the lane's stream when the batch is
         finalized (e.g. the all-gather of the result rows).  `timers` forces an eager (uncaptured) step.
         sync_inputs=False skips the wait on the caller's stream (inputs already complete in HBM)."""
         import torch
-        i = self.k % self.depth
-        self.k += 1
+        i = self.k % self.depth if lane is None else int(lane) % self.depth      # lane=: a fixed batch -> lane map
+        self.k += 1                                                              # (one captured graph per batch)
         self._finalize(i)
         st, ws = self.streams[i], self.ws[i]
         if sync_inputs:                                      # inputs produced on the caller's stream; pass False when
@@ -231,6 +231,97 @@ class Lanes:
         cur = torch.cuda.current_stream()
         for st in self.streams:
             cur.wait_stream(st)
+
+
+class CorpusPass:
+    """One rank's share of a corpus-shaped pass: the loops of run_analysis / process_recording
+    (scripts/tda_eeg_audio_comparison.py:131-138, 63-122) turned inside out.  The rank's recordings are
+    resident in HBM as ONE batch per band -- eeg[b]: (n_rec * wpr, 47, 250), aud[b]: (n_rec * wpr, 250),
+    window (r * wpr + w) = the w-th selected window of local recording r -- and a pass is one `run_step` per band,
+    fed through `Lanes` (band b always on lane b % depth, so each band's launches are captured once).  The
+    (n_rec, n_bands, 48) block of result rows is all-gathered ONCE per pass (dist.all_gather_rows: RCCL over xGMI
+    on the GPU box), which replaces the reference's serial loop over recordings and the partial-file merge of
+    scripts/tda_eeg_classification_v2.py:608-638."""
+
+    def __init__(self, eeg, aud, wpr, device, ctx, depth=3, graph=True, my_recs=None, shards=None, n_total=None,
+                 gather=True, seg_off=None, **lane_kw):
+        import torch
+        self.eeg, self.aud, self.ctx = eeg, aud, ctx
+        self.n_bands = len(eeg)
+        n_win = eeg[0].shape[0]
+        assert all(e.shape[0] == n_win for e in eeg) and all(a.shape[0] == n_win for a in aud)
+        if seg_off is None:                       # wpr selected windows per recording-band
+            assert n_win % wpr == 0
+            seg_off = np.arange(0, n_win + 1, wpr, dtype=np.int32)
+        self.n_rec, self.n_win = len(seg_off) - 1, n_win
+        # big batches: the widening passes ride along with every step (a small strided grid each; their cost is
+        # noise next to a batch of thousands of windows, and no host round trip is needed)
+        lane_kw.setdefault("defer_retries", False)
+        self.lanes = Lanes(depth, n_win, seg_off, device, graph=graph, **lane_kw)
+        self.blocks = [torch.empty((self.n_rec, self.n_bands, RESULT_COLS), dtype=torch.float64, device=device)
+                       for _ in range(3)]
+        self.my_recs, self.shards, self.n_total = my_recs, shards, n_total
+        self.gather = gather and shards is not None and len(shards) > 1
+        self.passes = 0
+        self.gathered = None
+        self._open = {}
+
+    def _post(self, k, b, result):
+        """Runs on the lane's stream when band b of pass k has been verified: its rows join the pass' block; the
+        last band to arrive (any order) all-gathers the block."""
+        import torch
+        blk = self.blocks[k % len(self.blocks)]
+        blk[:, b].copy_(result)
+        st = self._open.setdefault(k, {"left": self.n_bands, "events": []})
+        ev = torch.cuda.Event()
+        ev.record()
+        st["events"].append(ev)
+        st["left"] -= 1
+        if st["left"] == 0:
+            cur = torch.cuda.current_stream()
+            for e in st["events"]:
+                cur.wait_event(e)
+            del self._open[k]
+            flat = blk.view(self.n_rec, self.n_bands * RESULT_COLS)
+            if self.gather:
+                from . import dist as tdist
+                self.gathered = tdist.all_gather_rows(flat, self.my_recs, self.shards, self.n_total)
+            else:
+                self.gathered = flat
+        return None
+
+    def step(self, timers=None):
+        """Enqueue one pass (one batch per band).  timers: optional {band index: stage-event dict} -- those bands
+        are launched eagerly with per-stage events (see run_step)."""
+        import functools
+        k = self.passes
+        self.passes += 1
+        for b in range(self.n_bands):
+            self.lanes.submit(self.eeg[b], self.aud[b], ctx=self.ctx, post=functools.partial(self._post, k, b),
+                              sync_inputs=False, lane=b, timers=(timers or {}).get(b))
+
+    def finish(self):
+        """Verify and publish everything in flight; returns the rows of the last pass:
+        (n_total or n_rec, n_bands * 48), recordings in the reference's order."""
+        self.lanes.drain()
+        return self.gathered
+
+
+def run_features_step(eeg_win, ws, ctx=None):
+    """The EEG half alone, as process_file_features needs it (scripts/tda_eeg_classification_v2.py:404-436,
+    BASELINE.json configs[2]): corr->dist -> Rips -> 11 features of H0 and of H1 -> mean/std over the windows of
+    every (recording, band) group.  Returns ws.feat44 (n_seg, 44)."""
+    import torch
+    from . import _lib
+    ctx = ctx or _lib.get_ctx()
+    engine.corr_dist_dev(eeg_win, ws.dist, None, ctx=ctx)
+    engine.rips_dm_dev(ws.dist, ws.eeg, ctx=ctx)
+    engine.features_dev(ws.eeg.h0, ws.eeg.c0, ws.fe0, ctx=ctx)
+    engine.features_dev(ws.eeg.h1, ws.eeg.c1, ws.fe1, ctx=ctx)
+    if not hasattr(ws, "feat44"):
+        ws.feat44 = torch.empty((ws.n_seg, 44), dtype=torch.float64, device=ws.device)
+    engine.aggregate_dev(ws.fe0, ws.fe1, ws.seg_off, ws.feat44, ctx=ctx)
+    return ws.feat44
 
 
 STAGES = ["corr_dist", "rips_eeg", "features_eeg", "tau", "rips_audio", "features_audio", "wasserstein_h0",

@@ -47,3 +47,60 @@ def audio_windows_all_bands(n_per_band, seed=42):
         wins.append(audio_windows(n_per_band, band, seed + 1000 * bi))
         band_id += [bi] * n_per_band
     return np.concatenate(wins), np.array(band_id)
+
+
+# --------------------------------------------------------------------------------------------
+# corpus-shaped workloads (BASELINE.json configs[2], configs[4])
+# --------------------------------------------------------------------------------------------
+BANDS = list(FREQ_BANDS)
+
+
+def corpus_window_counts(n_rec=1416, seed=42):
+    """Windows per recording with the corpus' shape (results/preprocessing_metadata.csv: 710 slow recordings
+    with 65-89 windows, 706 fast ones with 39-54), slow ones first as scripts/tda_eeg_classification_v2.py:532-535
+    lists them."""
+    rng = np.random.default_rng(seed)
+    n_slow = (n_rec * 710 + 1415) // 1416
+    slow = rng.integers(65, 90, n_slow)
+    fast = rng.integers(39, 55, n_rec - n_slow)
+    return np.concatenate([slow, fast]).astype(np.int64)
+
+
+def corpus_audio(n_rec, n_per_rec, bands=BANDS, seed=4242, n_t=N_T):
+    """{band: (n_rec, n_per_rec, n_t) float64}: band-limited noise (Butterworth-4 at the band edges, zero phase), so
+    that the delay tau of compute_tau lands in the observed ranges (gamma 2 ... delta 27-102)
+    and the Takens clouds span 23 ... 123 points.  The SAME array on every rank (the recordings are dealt
+    afterwards), so the total work does not depend on the number of GPUs."""
+    from scipy import signal
+    nyq = FS / 2
+    out = {}
+    stride = n_t - 2                                      # the selected windows of a recording hardly overlap
+    for bi, band in enumerate(bands):
+        lo, hi = FREQ_BANDS[band]
+        b, a = signal.butter(4, [max(lo / nyq, 0.001), min(hi / nyq, 0.999)], btype="band")
+        rng = np.random.default_rng(seed + 1000 * bi)
+        need = 1000 + n_t + stride * (n_rec * n_per_rec - 1)
+        x = signal.filtfilt(b, a, rng.standard_normal(need))
+        idx = 500 + stride * np.arange(n_rec * n_per_rec)[:, None] + np.arange(n_t)[None, :]
+        out[band] = np.ascontiguousarray(x[idx].reshape(n_rec, n_per_rec, n_t))
+    return out
+
+
+def corpus_eeg_dev(rec_ids, n_per_rec, n_bands, device, seed=42, n_ch=N_CH, n_t=N_T):
+    """List (per band) of (len(rec_ids) * n_per_rec, n_ch, n_t) float64 tensors in HBM: X = A S + 0.5 E with 8
+    latent sources and A fixed per recording (the `latent` kind of eeg_windows), drawn on the GPU from a
+    generator seeded per RECORDING -- a recording's windows are the same whichever rank owns it.  torch is
+    the random-number plumbing here; nothing of the hot path runs in it."""
+    import torch
+    f64 = dict(dtype=torch.float64, device=device)
+    out = [torch.empty((len(rec_ids) * n_per_rec, n_ch, n_t), **f64) for _ in range(n_bands)]
+    g = torch.Generator(device=device)
+    for i, rec in enumerate(rec_ids):
+        g.manual_seed(int(seed) * 1000003 + int(rec))
+        A = torch.randn((n_ch, 8), generator=g, **f64)
+        S = torch.randn((n_bands, n_per_rec, 8, n_t), generator=g, **f64)
+        E = torch.randn((n_bands, n_per_rec, n_ch, n_t), generator=g, **f64)
+        X = torch.matmul(A, S).add_(E, alpha=0.5)
+        for b in range(n_bands):
+            out[b][i * n_per_rec:(i + 1) * n_per_rec] = X[b]
+    return out
