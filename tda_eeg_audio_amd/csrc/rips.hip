@@ -193,18 +193,20 @@ template <int NT>
 __device__ __forceinline__ bool wg_all(WgVote& v, bool p) { return !wg_any<NT>(v, !p); }
 
 // ---------------------------------------------------------------------------------
-// P1: stable LSD radix sort of the edges by their float32 length, in LDS, by the whole workgroup.
-// The keys stay where they are (key32[e], e = flat edge index tri2(a)+b); what moves is the 16-bit
-// edge (a << 8 | b), ping-ponging between two arrays, four key bits per pass.  The edges start in
-// flat-index order and every pass is stable, so equal lengths keep (a,b) order: the same total order
-// as sorting (key << 16 | a << 8 | b).  Thread t owns the B consecutive positions [t B, (t+1) B):
-//   count   16 digit counters per thread (8 bits each, two u64 registers) -> cnt[digit][t]
-//   scan    exclusive prefix sum over cnt in (digit-major, thread-minor) order = first destination of every
-//           (digit, thread); 16 consecutive entries per thread, wave scan on the DPP network
-//   scatter positions again in order: destination = cnt[digit][t] + (equal digits seen before in this thread)
-// A pass whose digit is the same for every edge (the top bits of lengths in (0, 2]) costs one barrier.
-// ~8 k compare-free LDS accesses per thread for 7,626 edges, where the bitonic network needed 373 k 64-bit
-// compare-exchanges (VALU bound).
+// P1 + P2: the rank of every edge in the order of (key, a, b), WITHOUT sorting.
+// The float32 lengths of one window are spread over (0, effective threshold]; a monotone linear map sends every edge
+// to one of NB >= E buckets (about one edge per bucket), so that
+//   rank(e) = #edges in earlier buckets + #edges of its own bucket that precede it in (key, flat index) order
+// (the flat index tri2(a)+b orders edges of equal length as (a,b) does).  Four sweeps over the edges:
+//   count    one LDS atomic per edge on a packed 16-bit counter (two buckets per word; counts < 65,536 never carry)
+//   scan     exclusive prefix over the buckets: every thread owns NB/NT consecutive buckets, wave scan on the DPP network
+//   scatter  members[slot] = e, slot from a returning atomic on the bucket's cursor (the order inside a bucket is
+//            arbitrary and never used)
+//   rank     every edge walks the few members of its bucket; rank[e] = r, ord[r] = (a << 8 | b)
+// ~60 vector instructions and ~15 LDS accesses per edge, against ~300 / ~56 for the seven-pass LSD radix sort this
+// replaces (and 10 barriers instead of 28).  Tie-heavy input degrades gracefully: a bucket of s equal lengths costs
+// s^2 comparisons -- bounded by E^2 / NT per thread when ALL lengths are equal.
+// Edges longer than the effective threshold take no part (rank RANK_NONE).
 // ---------------------------------------------------------------------------------
 __device__ __forceinline__ int wave_incl_scan_i32(int v)
 {
@@ -218,65 +220,20 @@ __device__ __forceinline__ int wave_incl_scan_i32(int v)
 #undef TDA_DPP_ADD_
     return v;
 }
+
 __device__ __forceinline__ int edge_flat(u32 pk) { return tri2((int)(pk >> 8)) + (int)(pk & 255u); }
 
-// key32: E keys; ia: E edges in flat order on entry; ib: second array; cnt: 16 * NT u16; wsum: NT/64 ints.
-// Returns the array that holds the sorted edges.
-template <int NT>
-__device__ u16* radix_sort_lds(const u32* key32, u16* ia, u16* ib, u16* cnt, int* wsum, u32* vote_slots, int E)
-{
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int B = (E + NT - 1) / NT;                  // positions per thread (<= 32)
-    const int p0 = tid * B, p1 = (p0 + B < E) ? p0 + B : E;
-    u16* cur = ia;
-    u16* nxt = ib;
-    if (E < 2) return cur;
-    WgVote vote{vote_slots, 0};
-    for (int shift = 0; shift < 32; shift += 4) {
-        // ---- count ----
-        u64 c0 = 0ull, c1 = 0ull;                     // digits 0..7 / 8..15, 8 bits each
-        const int dfirst = (int)((key32[edge_flat(cur[0])] >> shift) & 15u);
-        bool same = true;
-#pragma unroll 4
-        for (int p = p0; p < p1; ++p) {
-            const int d = (int)((key32[edge_flat(cur[p])] >> shift) & 15u);
-            same = same && d == dfirst;
-            const u64 one = 1ull << (8 * (d & 7));
-            if (d < 8) c0 += one; else c1 += one;
-        }
-#pragma unroll
-        for (int d = 0; d < 16; ++d) cnt[d * NT + tid] = (u16)(((d < 8 ? c0 : c1) >> (8 * (d & 7))) & 255ull);
-        if (wg_all<NT>(vote, same)) continue;                    // every edge has this digit: nothing moves
-        // ---- scan: entries [16 t, 16 t + 16) of the (digit-major, thread-minor) table ----
-        int loc[16], s = 0;
-#pragma unroll
-        for (int k = 0; k < 16; ++k) { loc[k] = s; s += (int)cnt[16 * tid + k]; }
-        const int incl = wave_incl_scan_i32(s);
-        if (lane == 63) wsum[wave] = incl;
-        __syncthreads();
-        int basep = incl - s;
-        for (int w = 0; w < wave; ++w) basep += wsum[w];
-#pragma unroll
-        for (int k = 0; k < 16; ++k) cnt[16 * tid + k] = (u16)(basep + loc[k]);
-        __syncthreads();
-        // ---- scatter ----
-        c0 = 0ull; c1 = 0ull;
-        const u16* __restrict__ src = cur;
-        u16* __restrict__ dstp = nxt;
-#pragma unroll 4
-        for (int p = p0; p < p1; ++p) {
-            const u32 pk = src[p];
-            const int d = (int)((key32[edge_flat(pk)] >> shift) & 15u);
-            const int sh = 8 * (d & 7);
-            const int seen = (int)(((d < 8 ? c0 : c1) >> sh) & 255ull);
-            if (d < 8) c0 += 1ull << sh; else c1 += 1ull << sh;
-            dstp[(int)cnt[d * NT + tid] + seen] = (u16)pk;
-        }
-        __syncthreads();
-        u16* t_ = cur; cur = nxt; nxt = t_;
+// monotone map from a sortable key in [kmin, teff] to a bucket in [0, NB)
+struct Bucketer {
+    float dmin, scale, top;
+    __device__ __forceinline__ int operator()(u32 key) const
+    {
+        // fminf returns the other operand for a NaN (0 * inf when all lengths are equal or the threshold is infinite)
+        const float x = fminf((sortable_f32(key) - dmin) * scale, top);
+        const int b = (int)x;
+        return b < 0 ? 0 : b;
     }
-    return cur;
-}
+};
 
 // Effective threshold = min(thresh, enclosing radius).  At the enclosing radius
 // r_enc = min_v max_u d(v,u) some vertex is adjacent to every other one, the complex is a cone and
@@ -284,9 +241,11 @@ __device__ u16* radix_sort_lds(const u32* key32, u16* ia, u16* ib, u16* cnt, int
 // apex with zero persistence.  Edges longer than r_enc therefore cannot contribute a diagram row
 // (ripser applies the same cut when no threshold is given); dropping them shortens the sweep.
 // vmax[v] (u32 sortable keys, LDS) must hold max_u key(v,u) on entry.  Returns the number of edges
-// whose key is <= the effective threshold (workgroup-uniform) .
+// whose key is <= the effective threshold (workgroup-uniform); teff_out / kmin_out: that threshold and the
+// smallest key of the window.  red: u32[4] scratch in LDS.
 template <int NT>
-__device__ int count_effective_edges(const u32* key32, int E, int n, u32 tkey, const u32* vmax, int* red)
+__device__ int count_effective_edges(const u32* key32, int E, int n, u32 tkey, const u32* vmax, u32* red, u32& teff_out,
+                                     u32& kmin_out)
 {
     const int tid = threadIdx.x;
     // enclosing radius: every wave takes the minimum over the (<= 128) vertices, two per lane, on the DPP network
@@ -295,13 +254,100 @@ __device__ int count_effective_edges(const u32* key32, int E, int n, u32 tkey, c
     const u32 renc = wave_min_u32_dpp(m0 < m1 ? m0 : m1);
     const u32 teff = renc < tkey ? renc : tkey;
     int ev = 0;
-    for (int e = tid; e < E; e += NT) ev += (key32[e] <= teff) ? 1 : 0;
-    if (tid == 0) *red = 0;
+    u32 kmin = 0xffffffffu;
+    for (int e = tid; e < E; e += NT) { const u32 k = key32[e]; ev += (k <= teff) ? 1 : 0; kmin = k < kmin ? k : kmin; }
+    if (tid == 0) { red[0] = 0u; red[1] = 0xffffffffu; }
     __syncthreads();
     ev = wave_incl_scan_i32(ev);                      // lane 63 holds the wave's sum
-    if (lane == 63) atomicAdd(red, ev);
+    kmin = wave_min_u32_dpp(kmin);
+    if (lane == 63) { atomicAdd(&red[0], (u32)ev); atomicMin(&red[1], kmin); }
     __syncthreads();
-    return *red;
+    teff_out = teff;
+    kmin_out = red[1];
+    return (int)red[0];
+}
+
+// key32: E keys (flat index order).  members: E u16 (may share its LDS with ord).  cursor: NB u16 (as NB/2 packed
+// words).  wsum: NT/64 ints.
+template <int NT, int NB, bool WANT_KEYS>
+__device__ void rank_edges(const u32* key32, int E, u32 teff, u32 kmin, u16* members, u32* cursor, int* wsum, u16* rank,
+                           u16* ord, u32* skey)
+{
+    static_assert(NB % (2 * NT) == 0, "every thread scans whole words");
+    constexpr int WPT = NB / NT / 2;                  // packed words per thread in the scan
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    Bucketer bk;
+    bk.dmin = sortable_f32(kmin);
+    bk.top = (float)(NB - 1);
+    bk.scale = bk.top / (sortable_f32(teff) - bk.dmin);
+    for (int i = tid; i < NB / 2; i += NT) cursor[i] = 0u;
+    __syncthreads();
+    // ---- count ----
+    for (int e = tid; e < E; e += NT) {
+        const u32 k = key32[e];
+        if (k <= teff) { const int b = bk(k); atomicAdd(&cursor[b >> 1], 1u << (16 * (b & 1))); }
+    }
+    __syncthreads();
+    // ---- scan ----
+    {
+        u32 w[WPT];
+        int s = 0;
+#pragma unroll
+        for (int i = 0; i < WPT; ++i) {
+            const u32 x = cursor[tid * WPT + i];
+            const int c0 = (int)(x & 0xffffu), c1 = (int)(x >> 16);
+            w[i] = (u32)s | ((u32)(s + c0) << 16);    // exclusive prefix inside the thread
+            s += c0 + c1;
+        }
+        const int incl = wave_incl_scan_i32(s);
+        if (lane == 63) wsum[wave] = incl;
+        __syncthreads();
+        int basep = incl - s;
+        for (int q = 0; q < wave; ++q) basep += wsum[q];
+        const u32 add = (u32)basep * 0x00010001u;     // both halves (sums stay below 65,536)
+#pragma unroll
+        for (int i = 0; i < WPT; ++i) cursor[tid * WPT + i] = w[i] + add;
+    }
+    __syncthreads();
+    // ---- scatter: afterwards cursor[b] = end of bucket b = start of bucket b + 1 ----
+    for (int e = tid; e < E; e += NT) {
+        const u32 k = key32[e];
+        if (k <= teff) {
+            const int b = bk(k), sh = 16 * (b & 1);
+            const u32 old = atomicAdd(&cursor[b >> 1], 1u << sh);
+            members[(old >> sh) & 0xffffu] = (u16)e;
+        }
+    }
+    __syncthreads();
+    // ---- rank ----
+    const u16* cur16 = reinterpret_cast<const u16*>(cursor);
+    for (int e = tid; e < E; e += NT) {
+        const u32 k = key32[e];
+        u32 r = RANK_NONE;
+        if (k <= teff) {
+            const int b = bk(k);
+            const int lo = b ? (int)cur16[b - 1] : 0, hi = (int)cur16[b];
+            int c = 0;
+            for (int j = lo; j < hi; ++j) {
+                const u32 m = members[j];
+                const u32 km = key32[m];
+                c += (km < k || (km == k && m < (u32)e)) ? 1 : 0;
+            }
+            r = (u32)(lo + c);
+        }
+        rank[e] = (u16)r;
+    }
+    __syncthreads();                                  // ord may overlay `members`: every read of it is done
+    // ---- ord (and the sorted keys) from the rank table ----
+    for (int e = tid; e < E; e += NT) {
+        const u32 r = rank[e];
+        if (r != RANK_NONE) {
+            const int a = edge_row(e);
+            ord[r] = (u16)((a << 8) | (e - tri2(a)));
+            if (WANT_KEYS) skey[r] = key32[e];
+        }
+    }
+    __syncthreads();
 }
 
 struct RipsOut {
@@ -311,7 +357,7 @@ struct RipsOut {
 };
 
 struct RipsLayout {
-    int off_ia, off_ib;                         // sort phase: keys at 0, then the two edge arrays
+    int off_members;                            // ranking phase: keys at 0, then the bucket members
     int off_rank, off_ord, off_aux, off_misc;   // sweep phase: psi at 0, rank, ord; then aux and misc
     int total;
 };
@@ -322,7 +368,7 @@ struct RipsLayout {
 #define MISC_WV (512 + 128)                                  // 64 B: wave sums of the sort, then the vote slots of the sweep
 #define MISC_MIN (512 + 192)                                 // u32[4]: reductions; list count / earliest key
 #define MISC_DONE (512 + 208)                                // u8 done[NT_MAX]
-#define MISC_SORTCNT (512 + 224)                             // sort phase only: u16 cnt[16 * NT] (over the sweep's part)
+#define MISC_SORTCNT (512 + 224)                             // ranking phase only: u16 cursor[NB] (over the sweep's part)
 #define MISC_SHARED (MISC_DONE + NT_MAX)                     // SweepShared (96 B)
 #define MISC_CKEY (MISC_SHARED + 96)                         // float ckey[NT_MAX]: lengths of this chunk's candidate edges
 #define MISC_LIST MISC_CKEY                                  // phase d reuses ckey + the tail: triangle list, then image table
@@ -1161,47 +1207,6 @@ __device__ void rips_sweep(int n, int E, int Ev, const u16* rank, const u16* ord
     out_k0 = k0; out_k1 = k1; out_status = status;
 }
 
-// rank (triangular: rank[tri2(a) + b] = position of edge (a,b), a > b; RANK_NONE beyond the effective
-// threshold), ord (ord[r] = a << 8 | b) and, for distance matrices, skey[r] from the sorted edge array.
-// rank / ord (and psi) overlay the sort arrays, so every thread first pulls its positions into registers.
-// STAGE: psi is narrower than 8 B per edge, so rank / ord overlay the sort arrays and every thread first pulls
-// its positions into registers; otherwise they lie beyond the sort arrays (4E + 2E + 2E bytes) and are written
-// directly.
-template <int NT, bool WANT_KEYS, bool STAGE>
-__device__ void unpack_sorted(const u16* sorted, const u32* key32, int E, int Ev, u16* rank, u16* ord, u32* skey)
-{
-    const int tid = threadIdx.x;
-    if (STAGE) {
-        constexpr int MAXPT = STAGE ? (TDA_MAX_POINTS * (TDA_MAX_POINTS - 1) / 2 + NT - 1) / NT : 1;
-        u32 held[MAXPT], hkey[WANT_KEYS ? MAXPT : 1];
-#pragma unroll
-        for (int k = 0; k < MAXPT; ++k) {
-            const int e = tid + k * NT;
-            held[k] = e < E ? (u32)sorted[e] : 0u;
-            if (WANT_KEYS) hkey[k] = e < E ? key32[edge_flat(held[k])] : 0u;
-        }
-        __syncthreads();
-#pragma unroll
-        for (int k = 0; k < MAXPT; ++k) {
-            const int e = tid + k * NT;
-            if (e < E) {
-                rank[edge_flat(held[k])] = (e < Ev) ? (u16)e : (u16)RANK_NONE;
-                ord[e] = (u16)held[k];
-                if (WANT_KEYS) skey[e] = hkey[k];
-            }
-        }
-    } else {
-        for (int e = tid; e < E; e += NT) {
-            const u32 pk = sorted[e];
-            const int fl = edge_flat(pk);
-            if (WANT_KEYS) skey[e] = key32[fl];
-            rank[fl] = (e < Ev) ? (u16)e : (u16)RANK_NONE;
-            ord[e] = (u16)pk;
-        }
-    }
-    __syncthreads();
-}
-
 // ---------------------------------------------------------------------------------
 // distance-matrix flavour (EEG): LDS = [S | psi] [ord] [rank] [skey] [misc]
 // ---------------------------------------------------------------------------------
@@ -1217,15 +1222,14 @@ __device__ void rips_dm_window(unsigned char* smem, const int win, const double*
     const int tid = threadIdx.x;
     const int E = tri2(n);
     u32* key32 = reinterpret_cast<u32*>(smem);
-    u16* ia = reinterpret_cast<u16*>(smem + L.off_ia);
-    u16* ib = reinterpret_cast<u16*>(smem + L.off_ib);
+    u16* members = reinterpret_cast<u16*>(smem + L.off_members);
     Psi<W, WT>* psi = reinterpret_cast<Psi<W, WT>*>(smem);
     u16* rank = reinterpret_cast<u16*>(smem + L.off_rank);
     u16* ord = reinterpret_cast<u16*>(smem + L.off_ord);
     u32* skey = reinterpret_cast<u32*>(smem + L.off_aux);
     unsigned char* misc = smem + L.off_misc;
-    int* red = reinterpret_cast<int*>(misc + MISC_MIN);
-    u16* cnt = reinterpret_cast<u16*>(misc + MISC_SORTCNT);
+    u32* red = reinterpret_cast<u32*>(misc + MISC_MIN);
+    u32* cursor = reinterpret_cast<u32*>(misc + MISC_SORTCNT);
     int* wsum = reinterpret_cast<int*>(misc + MISC_WV);
 
     PROF_BEGIN();
@@ -1246,17 +1250,15 @@ __device__ void rips_dm_window(unsigned char* smem, const int win, const double*
         }
         const u32 sk = f32_sortable((float)v);
         key32[e] = sk;
-        ia[e] = (u16)((a << 8) | b);
         atomicMax(&vmax[a], sk);
         atomicMax(&vmax[b], sk);
     }
     __syncthreads();
-    const int Ev = count_effective_edges<NT>(key32, E, n, tkey, vmax, red);
+    u32 teff, kmin;
+    const int Ev = count_effective_edges<NT>(key32, E, n, tkey, vmax, red, teff, kmin);
     PROF_MARK(0);
-    const u16* sorted = radix_sort_lds<NT>(key32, ia, ib, cnt, wsum, reinterpret_cast<u32*>(misc + MISC_CAND), E);
+    rank_edges<NT, (NVW == 1 ? 2048 : 8192), true>(key32, E, teff, kmin, members, cursor, wsum, rank, ord, skey);
     PROF_MARK(1);
-    unpack_sorted<NT, true, false>(sorted, key32, E, Ev, rank, ord, skey);
-    PROF_MARK(2);
     int k0, k1, st;
     KeyFromLds kf{skey};
     rips_sweep<NT, NVW, W, WT>(n, E, Ev, rank, ord, psi, misc, kf,
@@ -1347,14 +1349,13 @@ __device__ void rips_cloud_window(unsigned char* smem, const int win, const doub
 {
     const int tid = threadIdx.x;
     u32* key32 = reinterpret_cast<u32*>(smem);
-    u16* ia = reinterpret_cast<u16*>(smem + L.off_ia);
-    u16* ib = reinterpret_cast<u16*>(smem + L.off_ib);
+    u16* members = reinterpret_cast<u16*>(smem + L.off_members);
     Psi<W, WT>* psi = reinterpret_cast<Psi<W, WT>*>(smem);
     u16* rank = reinterpret_cast<u16*>(smem + L.off_rank);
     u16* ord = reinterpret_cast<u16*>(smem + L.off_ord);
     double* pts = reinterpret_cast<double*>(smem + L.off_aux);
     unsigned char* misc = smem + L.off_misc;
-    int* red = reinterpret_cast<int*>(misc + MISC_MIN);
+    u32* red = reinterpret_cast<u32*>(misc + MISC_MIN);
     double* mm = reinterpret_cast<double*>(misc + MISC_CKEY);    // min/max scratch (before the sweep)
 
     double* h0 = out.h0 + (size_t)win * out.h0_cap * 2;
@@ -1422,7 +1423,7 @@ __device__ void rips_cloud_window(unsigned char* smem, const int win, const doub
     const u32 tkey = f32_sortable(thresh);
     KeyFromPts kf{pts, dim};
     u32* vmax = reinterpret_cast<u32*>(misc + MISC_COMP);
-    u16* cnt = reinterpret_cast<u16*>(misc + MISC_SORTCNT);
+    u32* cursor = reinterpret_cast<u32*>(misc + MISC_SORTCNT);
     int* wsum = reinterpret_cast<int*>(misc + MISC_WV);
     if (tid < 128) vmax[tid] = 0u;
     __syncthreads();
@@ -1430,18 +1431,16 @@ __device__ void rips_cloud_window(unsigned char* smem, const int win, const doub
         const int a = edge_row(e), b = e - tri2(a);
         const u32 sk = f32_sortable(kf(0, a, b));
         key32[e] = sk;
-        ia[e] = (u16)((a << 8) | b);
         atomicMax(&vmax[b], sk);          // (consecutive lanes: consecutive b, no conflict)
     }
     __syncthreads();
     row_maxima<NT>(key32, vmax, P);
     __syncthreads();
-    const int Ev = count_effective_edges<NT>(key32, E, P, tkey, vmax, red);
+    u32 teff, kmin;
+    const int Ev = count_effective_edges<NT>(key32, E, P, tkey, vmax, red, teff, kmin);
     PROF_MARK(0);
-    const u16* sorted = radix_sort_lds<NT>(key32, ia, ib, cnt, wsum, reinterpret_cast<u32*>(misc + MISC_CAND), E);
+    rank_edges<NT, 8192, false>(key32, E, teff, kmin, members, cursor, wsum, rank, ord, nullptr);
     PROF_MARK(1);
-    unpack_sorted<NT, false, (sizeof(WT) * W < 8)>(sorted, key32, E, Ev, rank, ord, nullptr);
-    PROF_MARK(2);
     int k0, k1, st;
     if (P <= 64)
         rips_sweep<NT, 1, W, WT>(P, E, Ev, rank, ord, psi, misc, kf, h0, out.h0_cap, h1, out.h1_cap, k0, k1, st);
@@ -1534,20 +1533,20 @@ static RipsLayout make_layout(int n, int psi_bytes_per_edge, int aux_bytes, int 
     RipsLayout L;
     const int E = n * (n - 1) / 2;
     const int psi_bytes = E * psi_bytes_per_edge;
-    // sort phase:  [key32 4E][edges 2E][edges 2E]      sweep phase:  [psi][rank 2E][ord 2E]
-    // both start at 0 (unpack_sorted stages through registers); aux (point cloud / sorted keys) and misc follow.
-    // The digit table of the sort (16 * NT u16) lies over the part of misc that only the sweep uses.
-    L.off_ia = 4 * E;                                  // packed: the sort arrays end at 8E exactly, so that they stay
-    L.off_ib = 6 * E;                                  // below rank / ord whenever psi has >= 8 bytes per edge
-    const int sort_end = align16(8 * E);
+    // ranking phase:  [key32 4E] .. [members 2E]      sweep phase:  [psi][rank 2E][ord 2E]
+    // rank is written while the bucket members are still read, ord afterwards: with 4-byte class vectors the
+    // members take the place of ord, otherwise they follow the keys (rank / ord lie beyond 8E then).
+    // aux (point cloud / sorted keys) and misc follow; the bucket cursors (NB u16) lie over the part of misc that
+    // only the sweep uses.
     L.off_rank = align16(psi_bytes);
     L.off_ord = align16(L.off_rank + 2 * E);
+    L.off_members = psi_bytes_per_edge < 8 ? L.off_ord : 4 * E;
     int after_rank = align16(L.off_ord + 2 * E);
-    if (after_rank < sort_end) after_rank = sort_end;
     L.off_aux = after_rank;
     L.off_misc = align16(L.off_aux + aux_bytes);
     int misc_bytes = MISC_BYTES(8 * psi_bytes_per_edge);
-    if (misc_bytes < MISC_SORTCNT + 32 * NT) misc_bytes = MISC_SORTCNT + 32 * NT;
+    const int nb = (NT == 256 && n <= 64) ? 2048 : 8192;
+    if (misc_bytes < MISC_SORTCNT + 2 * nb) misc_bytes = MISC_SORTCNT + 2 * nb;
     L.total = align16(L.off_misc + misc_bytes);
     return L;
 }
