@@ -221,6 +221,27 @@ tda_status tda_features_batch_dev(tda_ctx* ctx, const double* dgm, const int* cn
 tda_status tda_features_batch(tda_ctx* ctx, const double* dgm, const int* cnt, int n_dgm,
                               int cap, double* feat);
 
+/* ---- finishing pass over the diagrams of a batch ---------------------------------
+ * Up to four diagram sets in ONE launch (one wavefront per diagram): for sets with order != 0 the H1 rows are put
+ * into ripser's order in place, and where feat != NULL the 11 scalars of extract_features are written -- what
+ * tda_features_batch_dev does for one set.  The driver of a whole step runs the Rips entry points under
+ * TDA_ORDER_DEFERRED and finishes the EEG H0 / EEG H1 / audio H1 diagrams of the batch with one call
+ * (scripts/tda_eeg_audio_comparison.py:92-99; scripts/tda_eeg_classification_v2.py:410-416).  `sets` is a host array
+ * of descriptors; the pointers inside are device pointers. */
+typedef struct {
+    double* rows;      /* (n_dgm, cap, 2) float64 */
+    const int* cnt;    /* (n_dgm) */
+    int cap;
+    int order;         /* 1: rows are H1 rows in emission order -> descending birth (ripser's order) */
+    double* feat;      /* (n_dgm, 11) float64 or NULL */
+} tda_diagram_set;
+tda_status tda_diagram_finish_dev(tda_ctx* ctx, const tda_diagram_set* sets, int n_sets, int n_dgm, void* stream);
+/* IN_CALL (default): every Rips entry point returns H1 rows in ripser's order (it launches the finishing pass for
+ * its own diagrams).  DEFERRED: rows stay in emission order until the caller's tda_diagram_finish_dev. */
+#define TDA_ORDER_IN_CALL  0
+#define TDA_ORDER_DEFERRED 1
+tda_status tda_set_h1_order(tda_ctx* ctx, int policy);
+
 /* ---- per-recording aggregation -------------------------------------------------
  * replaces the mean/std over windows of process_file_features
  * (tda_eeg_classification_v2.py:429-436).

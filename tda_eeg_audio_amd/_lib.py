@@ -61,6 +61,8 @@ SYMBOLS = {
     "tda_recording_rows_dev": (_I, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, _I, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "tda_set_retry_policy": (_I, [c_vp, _I]),
     "tda_set_retry_counter": (_I, [c_vp, c_vp]),
+    "tda_set_h1_order": (_I, [c_vp, _I]),
+    "tda_diagram_finish_dev": (_I, [c_vp, c_vp, _I, _I, c_vp]),
     "tda_tau_batch": (_I, [c_vp, c_vp, _I, _I, _I, c_vp]),
     "tda_features_batch_dev": (_I, [c_vp, c_vp, c_vp, _I, _I, c_vp, c_vp]),
     "tda_features_batch": (_I, [c_vp, c_vp, c_vp, _I, _I, c_vp]),
@@ -79,6 +81,11 @@ SYMBOLS = {
     "tda_set_kernel_probe": (_I, [c_vp, _I, c_vp, c_vp, c_vp]),
     "tda_stream_sync": (_I, [c_vp, c_vp]),
 }
+
+class DiagramSet(C.Structure):
+    """tda_diagram_set of include/tdaeeg.h."""
+    _fields_ = [("rows", c_vp), ("cnt", c_vp), ("cap", _I), ("order", _I), ("feat", c_vp)]
+
 
 _lib = None
 
@@ -143,6 +150,11 @@ class Context:
 
     def set_retry_policy(self, policy):
         self.check(self.lib.tda_set_retry_policy(self.h, int(policy)))
+
+    ORDER_IN_CALL, ORDER_DEFERRED = 0, 1
+
+    def set_h1_order(self, policy):
+        self.check(self.lib.tda_set_h1_order(self.h, int(policy)))
 
     def set_retry_counter(self, dev_ptr):
         """dev_ptr: device address of a zeroed u64[2] (or None): windows redone by the widening passes."""

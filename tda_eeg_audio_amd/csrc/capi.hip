@@ -59,6 +59,22 @@ tda_status tda_set_class_words(tda_ctx* ctx, int words_dm, int words_cloud)
     return TDA_OK;
 }
 
+tda_status tda_set_h1_order(tda_ctx* ctx, int policy)
+{
+    if (!ctx) return TDA_ERR_INVALID;
+    if (policy != TDA_ORDER_IN_CALL && policy != TDA_ORDER_DEFERRED) TDA_FAIL(ctx, TDA_ERR_INVALID, "unknown order policy");
+    ctx->h1_order = policy;
+    return TDA_OK;
+}
+
+tda_status tda_diagram_finish_dev(tda_ctx* ctx, const tda_diagram_set* sets, int n_sets, int n_dgm, void* stream)
+{
+    if (!ctx) return TDA_ERR_INVALID;
+    if (n_dgm < 0) TDA_FAIL(ctx, TDA_ERR_INVALID, "negative count");
+    if (n_sets && !sets) TDA_FAIL(ctx, TDA_ERR_INVALID, "null pointer");
+    return launch_diagram_finish(ctx, sets, n_sets, n_dgm, (hipStream_t)stream);
+}
+
 tda_status tda_set_retry_counter(tda_ctx* ctx, void* dev_counters)
 {
     if (!ctx) return TDA_ERR_INVALID;

@@ -15,6 +15,7 @@ struct tda_ctx {
     int words_cloud = 1;    // ... for point clouds
     int retry_policy = 0;   // TDA_RETRY_*
     unsigned long long* retry_ctr = nullptr;   // tda_set_retry_counter: device u64[2]
+    int h1_order = 0;       // TDA_ORDER_*
     // host-API staging workspace (grown on demand, only by the host-pointer twins)
     void* ws = nullptr;
     size_t ws_bytes = 0;
@@ -156,6 +157,7 @@ tda_status launch_tau_segments(tda_ctx*, const double*, const int*, int, int, in
 tda_status launch_recording_rows(tda_ctx*, const double*, const double*, const int*, const double*, const double*, const int*,
                                  int, double*, const int*, const int*, int*, hipStream_t);
 tda_status launch_features(tda_ctx*, const double*, const int*, int, int, double*, hipStream_t);
+tda_status launch_diagram_finish(tda_ctx*, const tda_diagram_set*, int, int, hipStream_t);
 tda_status launch_aggregate(tda_ctx*, const double*, const double*, const int*, int, double*, hipStream_t);
 tda_status launch_nanmean(tda_ctx*, const double*, const int*, int, double*, hipStream_t);
 tda_status launch_spearman(tda_ctx*, const double*, const double*, int, const int*, int, const int*, int, double*, hipStream_t);

@@ -1494,36 +1494,6 @@ rips_cloud_kernel(const double* __restrict__ src, const int* __restrict__ tau_or
 }
 
 // ---------------------------------------------------------------------------------
-// H1 rows -> ripser's order (descending birth; ties: descending death, then emission order)
-// ---------------------------------------------------------------------------------
-__global__ void __launch_bounds__(64)
-h1_order_kernel(double* __restrict__ h1, int h1_cap, const int* __restrict__ h1_cnt, int n_win)
-{
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    double* buf = reinterpret_cast<double*>(smem);
-    const int win = blockIdx.x;
-    if (win >= n_win) return;
-    const int lane = lane_id();
-    int k = h1_cnt[win];
-    k = k < h1_cap ? k : h1_cap;
-    if (k < 2) return;
-    double* rows = h1 + (size_t)win * h1_cap * 2;
-    for (int i = lane; i < 2 * k; i += 64) buf[i] = rows[i];
-    __syncthreads();
-    for (int i = lane; i < k; i += 64) {
-        const double bi = buf[2 * i], di = buf[2 * i + 1];
-        int rank = 0;
-        for (int j = 0; j < k; ++j) {
-            const double bj = buf[2 * j], dj = buf[2 * j + 1];
-            const bool before = (bj > bi) || (bj == bi && (dj > di || (dj == di && j < i)));
-            rank += before ? 1 : 0;
-        }
-        rows[2 * rank] = bi;
-        rows[2 * rank + 1] = di;
-    }
-}
-
-// ---------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------
 static inline int align16(int x) { return (x + 15) & ~15; }
@@ -1551,14 +1521,13 @@ static RipsLayout make_layout(int n, int psi_bytes_per_edge, int aux_bytes, int 
     return L;
 }
 
+// H1 rows -> ripser's order (descending birth; ties: descending death, then emission order): the finishing pass of
+// features.hip, unless the caller runs that pass itself for several diagram sets at once (tda_set_h1_order)
 static tda_status order_h1(tda_ctx* ctx, double* h1, int h1_cap, int* h1_cnt, int n_win, hipStream_t st)
 {
-    if (h1_cap < 2) return TDA_OK;
-    const size_t lds = (size_t)h1_cap * 16;
-    if (lds > 64 * 1024) TDA_FAIL(ctx, TDA_ERR_UNSUPPORTED, "h1_cap too large (max 4096 rows)");
-    hipLaunchKernelGGL(h1_order_kernel, dim3(n_win), dim3(64), lds, st, h1, h1_cap, h1_cnt, n_win);
-    TDA_HIP(ctx, hipGetLastError());
-    return TDA_OK;
+    if (h1_cap < 2 || ctx->h1_order == TDA_ORDER_DEFERRED) return TDA_OK;
+    tda_diagram_set one{h1, h1_cnt, h1_cap, 1, nullptr};
+    return launch_diagram_finish(ctx, &one, 1, n_win, st);
 }
 
 template <int NVW, int W>

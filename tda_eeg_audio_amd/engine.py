@@ -344,6 +344,19 @@ def features_dev(rows_t, cnt_t, feat_t=None, ctx=None):
     return feat_t
 
 
+def diagram_finish_dev(sets, ctx=None):
+    """ONE launch over up to four diagram sets: sets = [(rows_t (n, cap, 2), cnt_t (n,), order: bool, feat_t or
+    None), ...] -- H1 rows into ripser's order where order is set, extract_features where feat_t is given."""
+    ctx = ctx or get_ctx()
+    arr = (_lib.DiagramSet * len(sets))()
+    n = sets[0][0].shape[0]
+    for i, (rows_t, cnt_t, order, feat_t) in enumerate(sets):
+        assert rows_t.shape[0] == n and rows_t.is_contiguous()
+        arr[i].rows = rows_t.data_ptr(); arr[i].cnt = cnt_t.data_ptr(); arr[i].cap = rows_t.shape[1]
+        arr[i].order = int(bool(order)); arr[i].feat = feat_t.data_ptr() if feat_t is not None else None
+    ctx.check(ctx.lib.tda_diagram_finish_dev(ctx.h, C.cast(arr, C.c_void_p), len(sets), n, _stream()))
+
+
 def aggregate_dev(f0_t, f1_t, seg_off_t, out_t=None, ctx=None):
     import torch
     ctx = ctx or get_ctx()

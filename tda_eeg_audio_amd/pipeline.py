@@ -63,9 +63,11 @@ def run_step(eeg_win, audio_win, ws, ctx=None, max_lag=125, timers=None, retry="
     ctx = ctx or _lib.get_ctx()
     if retry == "first":
         ctx.set_retry_policy(ctx.RETRY_FIRST_PASS)
+    ctx.set_h1_order(ctx.ORDER_DEFERRED)         # one finishing pass for the three diagram sets of the batch
     try:
         return _run_step(eeg_win, audio_win, ws, ctx, max_lag, timers, retry)
     finally:
+        ctx.set_h1_order(ctx.ORDER_IN_CALL)
         if retry == "first":
             ctx.set_retry_policy(ctx.RETRY_AUTO)
 
@@ -92,18 +94,16 @@ def _run_step(eeg_win, audio_win, ws, ctx, max_lag, timers, retry):
     with torch.cuda.stream(side):
         stage("corr_dist", lambda: engine.corr_dist_dev(eeg_win, ws.dist, None, ctx=ctx))
         stage("rips_eeg", lambda: engine.rips_dm_dev(ws.dist, ws.eeg, ctx=ctx))
-
-        # everything that depends on the EEG diagrams only also stays on the side stream
-        def eeg_feats():
-            engine.features_dev(ws.eeg.h0, ws.eeg.c0, ws.fe0, ctx=ctx)
-            engine.features_dev(ws.eeg.h1, ws.eeg.c1, ws.fe1, ctx=ctx)
-        stage("features_eeg", eeg_feats)
     # tau from the first selected window of each recording-band (cmp:83), written per group and per window
     stage("tau", lambda: engine.tau_segments_dev(audio_win, ws.seg_off, max_lag, ws.tau_seg, ws.tau_win, ctx=ctx))
     stage("rips_audio", lambda: engine.takens_rips_dev(audio_win, ws.tau_win, ws.aud, ctx=ctx))
-    stage("features_audio", lambda: engine.features_dev(ws.aud.h1, ws.aud.c1, ws.fa1, ctx=ctx))
     if ws.overlap:
         main.wait_stream(side)
+    # H1 rows of both Rips stages into ripser's order + extract_features of EEG H0 / EEG H1 / audio H1
+    # (cmp:98-99, v2:415-416): one launch, one wavefront per diagram
+    stage("finish", lambda: engine.diagram_finish_dev([(ws.eeg.h0, ws.eeg.c0, False, ws.fe0),
+                                                        (ws.eeg.h1, ws.eeg.c1, True, ws.fe1),
+                                                        (ws.aud.h1, ws.aud.c1, True, ws.fa1)], ctx=ctx))
     stage("wasserstein_h0", lambda: engine.wasserstein_dev(ws.eeg.h0, ws.eeg.c0, ws.aud.h0, ws.aud.c0,
                                                            out_t=ws.w0, status_t=ws.ws0, ctx=ctx))
     stage("wasserstein_h1", lambda: engine.wasserstein_dev(ws.eeg.h1, ws.eeg.c1, ws.aud.h1, ws.aud.c1,
@@ -315,14 +315,16 @@ def run_features_step(eeg_win, ws, ctx=None):
     from . import _lib
     ctx = ctx or _lib.get_ctx()
     engine.corr_dist_dev(eeg_win, ws.dist, None, ctx=ctx)
-    engine.rips_dm_dev(ws.dist, ws.eeg, ctx=ctx)
-    engine.features_dev(ws.eeg.h0, ws.eeg.c0, ws.fe0, ctx=ctx)
-    engine.features_dev(ws.eeg.h1, ws.eeg.c1, ws.fe1, ctx=ctx)
+    ctx.set_h1_order(ctx.ORDER_DEFERRED)
+    try:
+        engine.rips_dm_dev(ws.dist, ws.eeg, ctx=ctx)
+    finally:
+        ctx.set_h1_order(ctx.ORDER_IN_CALL)
+    engine.diagram_finish_dev([(ws.eeg.h0, ws.eeg.c0, False, ws.fe0), (ws.eeg.h1, ws.eeg.c1, True, ws.fe1)], ctx=ctx)
     if not hasattr(ws, "feat44"):
         ws.feat44 = torch.empty((ws.n_seg, 44), dtype=torch.float64, device=ws.device)
     engine.aggregate_dev(ws.fe0, ws.fe1, ws.seg_off, ws.feat44, ctx=ctx)
     return ws.feat44
 
 
-STAGES = ["corr_dist", "rips_eeg", "features_eeg", "tau", "rips_audio", "features_audio", "wasserstein_h0",
-          "wasserstein_h1", "reduce"]
+STAGES = ["corr_dist", "rips_eeg", "tau", "rips_audio", "finish", "wasserstein_h0", "wasserstein_h1", "reduce"]
