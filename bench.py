@@ -208,7 +208,13 @@ def main():
         ev_log.append(timers)
     cur_events[0] = None
     torch.cuda.synchronize()
-    stage_ms = {s: sum(t[s][0].elapsed_time(t[s][1]) for t in ev_log) for s in pipeline.STAGES}    # per pass, bands alone
+    def _ms(t, s):
+        try:
+            return t[s][0].elapsed_time(t[s][1])
+        except Exception:                        # stage not on this path (fused / two-kernel EEG chain)
+            return 0.0
+    stage_ms = {s: sum(_ms(t, s) for t in ev_log) for s in pipeline.STAGES}    # per pass, band batches one at a time
+    stage_ms = {s: v for s, v in stage_ms.items() if v > 0.0}
     event_ms = [ctx.elapsed_ms(a, b) for a, b in probes]
     try:
         for _ in range(max(1, args.warmup)):

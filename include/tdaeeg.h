@@ -133,6 +133,18 @@ tda_status tda_rips_dm_batch(tda_ctx* ctx, const double* dm, int n_win, int n, d
                              int symmetrise, double* h0, int h0_cap, int* h0_cnt,
                              double* h1, int h1_cap, int* h1_cnt, int* status);
 
+/* ---- fused EEG window: samples -> correlation -> distance -> Rips H0/H1 in ONE launch -------------
+ * replaces, per window, compute_correlation_matrix + correlation_to_distance (nb2:86-122; the loop of
+ * process_file_graphs, nb2:198-207) followed by compute_eeg_persistence (scripts/utils.py:135-141): the distance
+ * matrix stays in LDS, 95.1 KB of HBM traffic per window instead of 129.4.  Same arithmetic, operation for
+ * operation, as tda_corr_dist_batch_dev + tda_rips_dm_batch_dev(symmetrise = 1): identical diagrams.
+ * win: (n_win, n_ch, n_t) float64, 33 <= n_ch <= 48 (the reference has 47), n_t <= 256 (250).
+ * dist / corr (nullable; corr needs dist): the matrices as tda_corr_dist_batch writes them, for callers that also
+ * want the graphs/<cond>/<rec>/<band>_distances.npy hand-off file.  Device pointers only. */
+tda_status tda_eeg_window_batch_dev(tda_ctx* ctx, const double* win, int n_win, int n_ch, int n_t, double thresh,
+                                    double* dist, double* corr, double* h0, int h0_cap, int* h0_cnt,
+                                    double* h1, int h1_cap, int* h1_cnt, int* status, void* stream);
+
 /* ---- Takens embedding + Rips (audio branch) ---------------------------------
  * replaces takens_embedding (scripts/utils.py:107-116) followed by
  * compute_audio_persistence (utils.py:123-132): per-column min-max to [0,1],

@@ -50,6 +50,7 @@
 // Class capacity ladder: a first pass, then widening passes that redo only flagged windows (tda_set_retry_policy).
 // No MFMA: this is irregular integer work; the roofline that binds it is LDS latency/issue.
 #include "common.h"
+#include "corr_dist_dev.h"
 #include <stdlib.h>
 
 #define NT_MAX 512            // largest workgroup (point-cloud flavour); distance-matrix flavour uses 256
@@ -1215,9 +1216,10 @@ struct KeyFromLds {
     __device__ __forceinline__ float operator()(int r, int, int) const { return sortable_f32(skey[r]); }
 };
 
+// everything after the keys: key32[e] (flat edge order) and vmax[v] = max_u key(v,u) are in LDS, barrier passed
 template <int NT, int NVW, int W, typename WT>
-__device__ void rips_dm_window(unsigned char* smem, const int win, const double* __restrict__ dm, int n, float thresh,
-                               int symmetrise, const RipsLayout& L, const RipsOut& out)
+__device__ void rips_dm_rest(unsigned char* smem, const int win, int n, float thresh, const u32* vmax, const RipsLayout& L,
+                             const RipsOut& out)
 {
     const int tid = threadIdx.x;
     const int E = tri2(n);
@@ -1231,10 +1233,34 @@ __device__ void rips_dm_window(unsigned char* smem, const int win, const double*
     u32* red = reinterpret_cast<u32*>(misc + MISC_MIN);
     u32* cursor = reinterpret_cast<u32*>(misc + MISC_SORTCNT);
     int* wsum = reinterpret_cast<int*>(misc + MISC_WV);
+    const u32 tkey = f32_sortable(thresh);
+    u32 teff, kmin;
+    PROF_RESUME();
+    const int Ev = count_effective_edges<NT>(key32, E, n, tkey, vmax, red, teff, kmin);
+    rank_edges<NT, (NVW == 1 ? 2048 : 8192), true>(key32, E, teff, kmin, members, cursor, wsum, rank, ord, skey);
+    PROF_MARK(1);
+    int k0, k1, st;
+    KeyFromLds kf{skey};
+    rips_sweep<NT, NVW, W, WT>(n, E, Ev, rank, ord, psi, misc, kf,
+                       out.h0 + (size_t)win * out.h0_cap * 2, out.h0_cap,
+                       out.h1 + (size_t)win * out.h1_cap * 2, out.h1_cap, k0, k1, st);
+    PROF_MARK(3);
+    PROF_COUNT(8, 1);
+    PROF_COUNT(9, E);
+    PROF_FLUSH();
+    if (tid == 0) { out.h0_cnt[win] = k0; out.h1_cnt[win] = k1; out.status[win] = st; }
+}
 
+template <int NT, int NVW, int W, typename WT>
+__device__ void rips_dm_window(unsigned char* smem, const int win, const double* __restrict__ dm, int n, float thresh,
+                               int symmetrise, const RipsLayout& L, const RipsOut& out)
+{
+    const int tid = threadIdx.x;
+    const int E = tri2(n);
+    u32* key32 = reinterpret_cast<u32*>(smem);
+    unsigned char* misc = smem + L.off_misc;
     PROF_BEGIN();
     const double* D = dm + (size_t)win * n * n;
-    const u32 tkey = f32_sortable(thresh);
     // P0. keys: utils.py:137-139 then ripser's float32 cast
     u32* vmax = reinterpret_cast<u32*>(misc + MISC_COMP);
     if (tid < 128) vmax[tid] = 0u;
@@ -1254,21 +1280,8 @@ __device__ void rips_dm_window(unsigned char* smem, const int win, const double*
         atomicMax(&vmax[b], sk);
     }
     __syncthreads();
-    u32 teff, kmin;
-    const int Ev = count_effective_edges<NT>(key32, E, n, tkey, vmax, red, teff, kmin);
     PROF_MARK(0);
-    rank_edges<NT, (NVW == 1 ? 2048 : 8192), true>(key32, E, teff, kmin, members, cursor, wsum, rank, ord, skey);
-    PROF_MARK(1);
-    int k0, k1, st;
-    KeyFromLds kf{skey};
-    rips_sweep<NT, NVW, W, WT>(n, E, Ev, rank, ord, psi, misc, kf,
-                       out.h0 + (size_t)win * out.h0_cap * 2, out.h0_cap,
-                       out.h1 + (size_t)win * out.h1_cap * 2, out.h1_cap, k0, k1, st);
-    PROF_MARK(3);
-    PROF_COUNT(8, 1);
-    PROF_COUNT(9, E);
-    PROF_FLUSH();
-    if (tid == 0) { out.h0_cnt[win] = k0; out.h1_cnt[win] = k1; out.status[win] = st; }
+    rips_dm_rest<NT, NVW, W, WT>(smem, win, n, thresh, vmax, L, out);
 }
 
 #ifdef TDA_DEBUG_PTS
@@ -1350,23 +1363,21 @@ __device__ __noinline__ void row_maxima(const u32* key32, u32* vmax, int P)
 // workgroup launches.
 // 64 and 128 classes: four waves per SIMD (128 VGPRs, no spills).  Five (96 VGPRs, 32 B of scratch per lane) paid while
 // the sweep spent its time at barriers; with the one-barrier votes four is 1 % faster end to end
-template <int NT, int NVW, int W, typename WT>
-__global__ void __launch_bounds__(NT, W <= 2 ? 4 : 1)
+template <int NT, int NVW, int W, typename WT, bool RETRY>
+__global__ void __launch_bounds__(NT, (W <= 2 && !RETRY) ? 4 : 1)
 rips_dm_kernel(const double* __restrict__ dm, int n_win, int n, float thresh, int symmetrise, RipsLayout L,
-               RipsOut out, int retry_only, unsigned long long* __restrict__ retry_ctr)
+               RipsOut out, unsigned long long* __restrict__ retry_ctr)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    if (!retry_only) {
-        for (int win = blockIdx.x; win < n_win; win += gridDim.x) {
+    if constexpr (!RETRY) {                          // one window per workgroup, no loop (see eeg_window_kernel)
+        if ((int)blockIdx.x < n_win)
+            rips_dm_window<NT, NVW, W, WT>(smem, (int)blockIdx.x, dm, n, thresh, symmetrise, L, out);
+    } else {
+        RETRY_SCAN_BEGIN(NT, out.status, n_win)
+            if (retry_ctr && threadIdx.x == 0) atomicAdd(retry_ctr, 1ull);
             rips_dm_window<NT, NVW, W, WT>(smem, win, dm, n, thresh, symmetrise, L, out);
-            __syncthreads();
-        }
-        return;
+        RETRY_SCAN_END()
     }
-    RETRY_SCAN_BEGIN(NT, out.status, n_win)
-        if (retry_ctr && threadIdx.x == 0) atomicAdd(retry_ctr, 1ull);
-        rips_dm_window<NT, NVW, W, WT>(smem, win, dm, n, thresh, symmetrise, L, out);
-    RETRY_SCAN_END()
 }
 
 template <int NT, int W, typename WT>
@@ -1489,11 +1500,11 @@ __device__ void rips_cloud_window(unsigned char* smem, const int win, const doub
 #ifndef CLOUD_WAVES
 #define CLOUD_WAVES 4
 #endif
-template <int NT, int W, typename WT>
-__global__ void __launch_bounds__(NT, CLOUD_WAVES)
+template <int NT, int W, typename WT, bool RETRY>
+__global__ void __launch_bounds__(NT, RETRY ? 2 : CLOUD_WAVES)
 rips_cloud_kernel(const double* __restrict__ src, const int* __restrict__ tau_or_npts, int n_win,
                   int n_t_or_pcap, int dim, int subsample, int mode, int normalise, float thresh,
-                  RipsLayout L, int p_max, int* __restrict__ n_points, RipsOut out, int retry_only,
+                  RipsLayout L, int p_max, int* __restrict__ n_points, RipsOut out,
                   unsigned long long* __restrict__ span, unsigned long long* __restrict__ retry_ctr)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1503,12 +1514,10 @@ rips_cloud_kernel(const double* __restrict__ src, const int* __restrict__ tau_or
     // store at the start: 512 simultaneous atomics on one address cost ~50 us per launch.)
     if (span && blockIdx.x == 0 && threadIdx.x == 0)      // workgroups are dispatched in order: 0 starts first
         atomicExch(&span[0], wall_clock64());
-    if (!retry_only) {
-        for (int win = blockIdx.x; win < n_win; win += gridDim.x) {
-            rips_cloud_window<NT, W, WT>(smem, win, src, tau_or_npts, n_t_or_pcap, dim, subsample, mode, normalise,
-                                         thresh, L, p_max, n_points, out);
-            __syncthreads();
-        }
+    if constexpr (!RETRY) {                               // one window per workgroup, no loop (see eeg_window_kernel)
+        if ((int)blockIdx.x < n_win)
+            rips_cloud_window<NT, W, WT>(smem, (int)blockIdx.x, src, tau_or_npts, n_t_or_pcap, dim, subsample, mode,
+                                         normalise, thresh, L, p_max, n_points, out);
     } else {
         RETRY_SCAN_BEGIN(NT, out.status, n_win)
             if (retry_ctr && threadIdx.x == 0) atomicAdd(retry_ctr + 1, 1ull);
@@ -1524,6 +1533,85 @@ rips_cloud_kernel(const double* __restrict__ src, const int* __restrict__ tau_or
             atomicAdd(&span[3], 1ull);
             atomicExch(&span[1], 0ull);
         }
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// Fused EEG window kernel: window (n_ch x n_t float64) -> correlation -> distance -> float32 keys -> Rips H0/H1, one
+// launch, one window per 256-thread workgroup; the distance matrix never leaves LDS (95.1 KB of algorithmic HBM
+// traffic per window instead of 129.4: SURVEY.md section 8d).  Replaces, per window, compute_correlation_matrix +
+// correlation_to_distance (notebooks/2_graph_construction.ipynb:86-122) followed by compute_eeg_persistence
+// (scripts/utils.py:135-141): the keys are float32((D[a][b] + D[b][a]) / 2) with D[i][j] = sqrt(2 (1 - r_ij)),
+// r_ij = (cov_ij / s_i) / s_j -- the arithmetic of corr_dist_kernel and of the key stage of rips_dm_kernel, operation
+// for operation, so the diagrams are bit-identical to the two-kernel path.  dist / corr (optional) receive the
+// matrices as corr_dist_kernel writes them.
+// ---------------------------------------------------------------------------------
+template <int NB, bool RES, int W>
+__device__ __forceinline__ void eeg_one_window(unsigned char* smem, const double* __restrict__ windows, int w, int n_ch,
+                                               int n_t, float thresh, const RipsLayout& L, const RipsOut& out,
+                                               double* __restrict__ dist, double* __restrict__ corr)
+{
+    const int tid = threadIdx.x, l = tid & 63, wv = tid >> 6;
+    PROF_BEGIN();
+    cd_window_products<NB, RES>(smem, windows + (size_t)w * n_ch * n_t, n_ch, n_t, n_t);
+    const double* accs = reinterpret_cast<const double*>(smem) + CdLayout<NB>::TILE;
+    const double* sdev = accs + CdLayout<NB>::ACCS + CdLayout<NB>::CP;
+    const double fact = 1.0 / (double)(n_t - 1);
+    auto dist_at = [&](int i, int j, double* r_out) {
+        double r = (accs[CdLayout<NB>::acc_index(i, j)] * fact / sdev[i]) / sdev[j];
+        r = r > 1.0 ? 1.0 : r; r = r < -1.0 ? -1.0 : r; if (r != r) r = 0.0;       // clip; nan_to_num (nb2:95)
+        if (r_out) *r_out = r;
+        double d = sqrt(2.0 * (1.0 - r));                                        // nb2:108
+        if (!(d > 0.0) || i == j) d = 0.0;                                       // nb2:119-120
+        return d;
+    };
+    // keys into the (free) tile area; the row maxima next to them, in what becomes the members array
+    const int E = tri2(n_ch);
+    u32* key32 = reinterpret_cast<u32*>(smem);
+    u32* vmax = reinterpret_cast<u32*>(smem + 4 * ((E + 3) & ~3));
+    if (tid < 128) vmax[tid] = 0u;
+    __syncthreads();
+    for (int e = tid; e < E; e += 256) {
+        const int a = edge_row(e), b = e - tri2(a);
+        double v = (dist_at(a, b, nullptr) + dist_at(b, a, nullptr)) / 2.0;      // utils.py:137
+        if (v < 0.0) v = 0.0;                                                    // utils.py:139
+        const u32 sk = f32_sortable((float)v);
+        key32[e] = sk;
+        atomicMax(&vmax[a], sk);
+        atomicMax(&vmax[b], sk);
+    }
+    if (dist) {                                  // the matrices themselves, when the caller wants them on disk
+        double* Dw = dist + (size_t)w * n_ch * n_ch;
+        double* Cw = corr ? corr + (size_t)w * n_ch * n_ch : nullptr;
+        for (int i = wv; i < n_ch; i += 4)
+            if (l < n_ch) {
+                double r;
+                const double d = dist_at(i, l, &r);
+                Dw[i * n_ch + l] = d;
+                if (Cw) Cw[i * n_ch + l] = r;
+            }
+    }
+    __syncthreads();
+    PROF_MARK(0);
+    rips_dm_rest<256, 1, W, u64>(smem, w, n_ch, thresh, vmax, L, out);
+}
+
+// RETRY = false: one window per workgroup and NO loop over windows -- with the loop the compiler hoists the address
+// arithmetic of the window fetch out of it and the kernel spills 141 registers (measured).
+template <int NB, bool RES, int W, bool RETRY>
+__global__ void __launch_bounds__(256, (W > 2 || RETRY) ? 1 : (RES ? 3 : 4))
+eeg_window_kernel(const double* __restrict__ windows, int n_win, int n_ch, int n_t, float thresh, RipsLayout L, RipsOut out,
+                  double* __restrict__ dist, double* __restrict__ corr, unsigned long long* __restrict__ retry_ctr)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    if constexpr (!RETRY) {
+        if ((int)blockIdx.x < n_win)
+            eeg_one_window<NB, RES, W>(smem, windows, (int)blockIdx.x, n_ch, n_t, thresh, L, out, dist, corr);
+    } else {
+        RETRY_SCAN_BEGIN(256, out.status, n_win)
+            if (retry_ctr && threadIdx.x == 0) atomicAdd(retry_ctr, 1ull);
+            eeg_one_window<NB, RES, W>(smem, windows, win, n_ch, n_t, thresh, L, out, dist, corr);
+        RETRY_SCAN_END()
     }
 }
 
@@ -1570,7 +1658,7 @@ static tda_status launch_dm_t(tda_ctx* ctx, const double* dm, int n_win, int n, 
 {
     const int NT = 256;
     const RipsLayout L = make_layout(n, W * 8, n * (n - 1) / 2 * 4, NT);
-    auto kern = rips_dm_kernel<256, NVW, W, u64>;
+    auto kern = retry_only ? rips_dm_kernel<256, NVW, W, u64, true> : rips_dm_kernel<256, NVW, W, u64, false>;
     if (L.total > 48 * 1024)
         TDA_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, L.total));
@@ -1581,7 +1669,7 @@ static tda_status launch_dm_t(tda_ctx* ctx, const double* dm, int n_win, int n, 
     {
         ProbeScope probe(ctx, retry_only ? -1 : TDA_PROBE_RIPS_DM, st);
         hipLaunchKernelGGL(kern, dim3(grid), dim3(NT), L.total, st, dm, n_win, n, thresh, symmetrise, L, out,
-                           retry_only, ctx->retry_ctr);
+                           ctx->retry_ctr);
     }
     TDA_HIP(ctx, hipGetLastError());
     return TDA_OK;
@@ -1632,6 +1720,66 @@ tda_status launch_rips_dm(tda_ctx* ctx, const double* dm, int n_win, int n, doub
     return order_h1(ctx, h1, h1_cap, h1_cnt, n_win, st);
 }
 
+template <int NB, bool RES, int W, bool RETRY>
+static tda_status launch_eeg_t(tda_ctx* ctx, const double* win, int n_win, int n_ch, int n_t, float thresh, RipsOut out,
+                               double* dist, double* corr, hipStream_t st)
+{
+    RipsLayout L = make_layout(n_ch, W * 8, n_ch * (n_ch - 1) / 2 * 4, 256);
+    if ((size_t)L.total < CdLayout<NB>::BYTES) L.total = (int)((CdLayout<NB>::BYTES + 15) & ~(size_t)15);
+    if (L.total > LDS_MAX) TDA_FAIL(ctx, TDA_ERR_UNSUPPORTED, "window too large for LDS");
+    auto kern = eeg_window_kernel<NB, RES, W, RETRY>;
+    if (L.total > 48 * 1024)
+        TDA_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, L.total));
+    const int rblocks = (n_win + 255) / 256, rgrid = W >= 8 ? 64 : 256;
+    const int grid = RETRY ? (rblocks < rgrid ? rblocks : rgrid) : n_win;
+    {
+        ProbeScope probe(ctx, RETRY ? -1 : TDA_PROBE_RIPS_DM, st);
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), L.total, st, win, n_win, n_ch, n_t, thresh, L, out, dist, corr,
+                           ctx->retry_ctr);
+    }
+    TDA_HIP(ctx, hipGetLastError());
+    return TDA_OK;
+}
+
+template <bool RES>
+static tda_status launch_eeg_ladder(tda_ctx* ctx, const double* win, int n_win, int n_ch, int n_t, float th, RipsOut out,
+                                    double* dist, double* corr, hipStream_t st)
+{
+    const bool do_first = ctx->retry_policy != TDA_RETRY_ONLY, do_ladder = ctx->retry_policy != TDA_RETRY_FIRST_PASS;
+    tda_status rc = TDA_OK;
+    const int W = ctx->words_dm >= 2 ? 2 : 1;
+    if (do_first)
+        rc = W == 1 ? launch_eeg_t<3, RES, 1, false>(ctx, win, n_win, n_ch, n_t, th, out, dist, corr, st)
+                    : launch_eeg_t<3, RES, 2, false>(ctx, win, n_win, n_ch, n_t, th, out, dist, corr, st);
+    // widening passes recompute the flagged windows from the samples (the matrix was never stored): 128 bits, then
+    // 512, which covers the theoretical maximum of 506 classes alive at once for 47 points
+    if (do_ladder && rc == TDA_OK && W == 1)
+        rc = launch_eeg_t<3, RES, 2, true>(ctx, win, n_win, n_ch, n_t, th, out, dist, corr, st);
+    if (do_ladder && rc == TDA_OK)
+        rc = launch_eeg_t<3, RES, 8, true>(ctx, win, n_win, n_ch, n_t, th, out, dist, corr, st);
+    return rc;
+}
+
+tda_status launch_eeg_windows(tda_ctx* ctx, const double* win, int n_win, int n_ch, int n_t, double thresh, double* dist,
+                              double* corr, double* h0, int h0_cap, int* h0_cnt, double* h1, int h1_cap, int* h1_cnt,
+                              int* status, hipStream_t st)
+{
+    if (n_win == 0) return TDA_OK;
+    if (n_ch < 33 || n_ch > 48) TDA_FAIL(ctx, TDA_ERR_UNSUPPORTED, "the fused EEG kernel takes 33..48 channels (the reference has 47); use tda_corr_dist_batch + tda_rips_dm_batch otherwise");
+    if (n_t < 2 || n_t > CD_RES_CHUNKS * CD_TCH) TDA_FAIL(ctx, TDA_ERR_UNSUPPORTED, "the fused EEG kernel takes windows of 2..256 samples (the reference has 250)");
+    if (h0_cap < n_ch) TDA_FAIL(ctx, TDA_ERR_INVALID, "h0_cap must be >= n_ch");
+    RipsOut out{h0, h0_cap, h0_cnt, h1, h1_cap, h1_cnt, status};
+    // the window is streamed twice (second time from L2 / the Infinity Cache): 128 VGPRs, four workgroups per CU --
+    // measured 2 % ahead of the form that keeps it in registers between the passes (148 VGPRs, three per CU), which
+    // stays available for measurements: TDA_EEG_RESIDENT=1
+    static const bool stream_twice = getenv("TDA_EEG_RESIDENT") == nullptr;
+    const tda_status rc = stream_twice ? launch_eeg_ladder<false>(ctx, win, n_win, n_ch, n_t, (float)thresh, out, dist, corr, st)
+                                       : launch_eeg_ladder<true>(ctx, win, n_win, n_ch, n_t, (float)thresh, out, dist, corr, st);
+    if (rc != TDA_OK) return rc;
+    return order_h1(ctx, h1, h1_cap, h1_cnt, n_win, st);
+}
+
 template <int W, typename WT>
 static tda_status launch_cloud_t(tda_ctx* ctx, const double* src, const int* aux, int n_win, int n_t_or_pcap,
                                  int dim, int subsample, int mode, int normalise, float thresh, int p_max,
@@ -1640,7 +1788,7 @@ static tda_status launch_cloud_t(tda_ctx* ctx, const double* src, const int* aux
     const int NT = CLOUD_NT;
     const RipsLayout L = make_layout(p_max, W * (int)sizeof(WT), p_max * dim * 8, NT);
     if (L.total > LDS_MAX) TDA_FAIL(ctx, TDA_ERR_UNSUPPORTED, "point cloud too large for LDS");
-    auto kern = rips_cloud_kernel<CLOUD_NT, W, WT>;
+    auto kern = retry_only ? rips_cloud_kernel<CLOUD_NT, W, WT, true> : rips_cloud_kernel<CLOUD_NT, W, WT, false>;
     if (L.total > 48 * 1024)
         TDA_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, L.total));
@@ -1649,7 +1797,7 @@ static tda_status launch_cloud_t(tda_ctx* ctx, const double* src, const int* aux
     {
         ProbeScope probe(ctx, retry_only ? -1 : TDA_PROBE_RIPS_CLOUD, st);
         hipLaunchKernelGGL(kern, dim3(grid), dim3(NT), L.total, st, src, aux, n_win, n_t_or_pcap, dim, subsample, mode,
-                           normalise, thresh, L, p_max, n_points, out, retry_only, probe.on ? probe.span : nullptr,
+                           normalise, thresh, L, p_max, n_points, out, probe.on ? probe.span : nullptr,
                            ctx->retry_ctr);
     }
     TDA_HIP(ctx, hipGetLastError());

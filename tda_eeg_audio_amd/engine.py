@@ -277,6 +277,20 @@ def rips_dm_dev(dm_t, out=None, thresh=MAX_EDGE_LENGTH, symmetrise=True, h1_cap=
     return out
 
 
+def eeg_window_dev(win_t, out=None, thresh=MAX_EDGE_LENGTH, h1_cap=DEFAULT_H1_CAP, dist_t=None, corr_t=None, ctx=None):
+    """Fused corr -> dist -> Rips of EEG windows (nb2:198-207 + utils.py:135-141), one launch; the matrices are
+    written only when dist_t (and corr_t) are given."""
+    import torch
+    ctx = ctx or get_ctx()
+    assert win_t.is_cuda and win_t.dtype == torch.float64 and win_t.is_contiguous()
+    n_win, n_ch, n_t = win_t.shape
+    out = out or DeviceDiagrams(n_win, n_ch, h1_cap, win_t.device)
+    ctx.check(ctx.lib.tda_eeg_window_batch_dev(ctx.h, _tp(win_t), n_win, n_ch, n_t, float(thresh), _tp(dist_t), _tp(corr_t),
+                                               _tp(out.h0), out.h0_cap, _tp(out.c0), _tp(out.h1), out.h1_cap, _tp(out.c1),
+                                               _tp(out.status), _stream()))
+    return out
+
+
 def takens_rips_dev(win_t, tau_t, out=None, dim=3, subsample=2, thresh=MAX_EDGE_LENGTH, h1_cap=DEFAULT_H1_CAP,
                     ctx=None):
     import torch

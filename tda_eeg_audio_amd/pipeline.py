@@ -32,7 +32,6 @@ class Workspace:
         self.rec_id = torch.from_numpy(rec_id.astype(np.int64)).to(device)
         self.first_idx = torch.from_numpy(seg_off[:-1].astype(np.int64)).to(device)
         f64 = dict(dtype=torch.float64, device=device)
-        self.dist = torch.empty((n_win, n_ch, n_ch), **f64)
         self.eeg = engine.DeviceDiagrams(n_win, n_ch, h1_cap, device)
         self.aud = engine.DeviceDiagrams(n_win, 128, h1_cap, device)
         self.tau_seg = torch.empty(self.n_seg, dtype=torch.int32, device=device)
@@ -49,6 +48,10 @@ class Workspace:
         self.side_stream = torch.cuda.Stream(device=device)
         import os
         self.overlap = os.environ.get("TDA_OVERLAP", "1") != "0"     # EEG chain on a side stream
+        # fused EEG window kernel (corr -> dist -> Rips in one launch, the matrix stays in LDS); "0": the two-kernel
+        # path through ws.dist (also taken when the channel count is outside the fused kernel's 33..48)
+        self.fused = os.environ.get("TDA_FUSED_EEG", "1") != "0" and 33 <= n_ch <= 48
+        self.dist = None if self.fused else torch.empty((n_win, n_ch, n_ch), **f64)
 
 
 def run_step(eeg_win, audio_win, ws, ctx=None, max_lag=125, timers=None, retry="auto"):
@@ -76,7 +79,7 @@ def _run_step(eeg_win, audio_win, ws, ctx, max_lag, timers, retry):
     import torch
 
     def stage(name, fn):
-        if timers is None:
+        if timers is None or name not in timers:
             return fn()
         s, e = timers[name]
         s.record()
@@ -92,8 +95,13 @@ def _run_step(eeg_win, audio_win, ws, ctx, max_lag, timers, retry):
     if ws.overlap:
         side.wait_stream(main)
     with torch.cuda.stream(side):
-        stage("corr_dist", lambda: engine.corr_dist_dev(eeg_win, ws.dist, None, ctx=ctx))
-        stage("rips_eeg", lambda: engine.rips_dm_dev(ws.dist, ws.eeg, ctx=ctx))
+        if ws.fused and eeg_win.shape[2] <= 256:
+            stage("eeg_window", lambda: engine.eeg_window_dev(eeg_win, ws.eeg, ctx=ctx))
+        else:
+            if ws.dist is None:
+                ws.dist = torch.empty((ws.n_win, eeg_win.shape[1], eeg_win.shape[1]), dtype=torch.float64, device=ws.device)
+            stage("corr_dist", lambda: engine.corr_dist_dev(eeg_win, ws.dist, None, ctx=ctx))
+            stage("rips_eeg", lambda: engine.rips_dm_dev(ws.dist, ws.eeg, ctx=ctx))
     # tau from the first selected window of each recording-band (cmp:83), written per group and per window
     stage("tau", lambda: engine.tau_segments_dev(audio_win, ws.seg_off, max_lag, ws.tau_seg, ws.tau_win, ctx=ctx))
     stage("rips_audio", lambda: engine.takens_rips_dev(audio_win, ws.tau_win, ws.aud, ctx=ctx))
@@ -314,10 +322,15 @@ def run_features_step(eeg_win, ws, ctx=None):
     import torch
     from . import _lib
     ctx = ctx or _lib.get_ctx()
-    engine.corr_dist_dev(eeg_win, ws.dist, None, ctx=ctx)
     ctx.set_h1_order(ctx.ORDER_DEFERRED)
     try:
-        engine.rips_dm_dev(ws.dist, ws.eeg, ctx=ctx)
+        if ws.fused and eeg_win.shape[2] <= 256:
+            engine.eeg_window_dev(eeg_win, ws.eeg, ctx=ctx)
+        else:
+            if ws.dist is None:
+                ws.dist = torch.empty((ws.n_win, eeg_win.shape[1], eeg_win.shape[1]), dtype=torch.float64, device=ws.device)
+            engine.corr_dist_dev(eeg_win, ws.dist, None, ctx=ctx)
+            engine.rips_dm_dev(ws.dist, ws.eeg, ctx=ctx)
     finally:
         ctx.set_h1_order(ctx.ORDER_IN_CALL)
     engine.diagram_finish_dev([(ws.eeg.h0, ws.eeg.c0, False, ws.fe0), (ws.eeg.h1, ws.eeg.c1, True, ws.fe1)], ctx=ctx)
@@ -327,4 +340,4 @@ def run_features_step(eeg_win, ws, ctx=None):
     return ws.feat44
 
 
-STAGES = ["corr_dist", "rips_eeg", "tau", "rips_audio", "finish", "wasserstein_h0", "wasserstein_h1", "reduce"]
+STAGES = ["eeg_window", "corr_dist", "rips_eeg", "tau", "rips_audio", "finish", "wasserstein_h0", "wasserstein_h1", "reduce"]

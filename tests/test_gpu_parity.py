@@ -544,3 +544,72 @@ def test_fused_row_kernels_equal_their_parts(ctx):
     assert np.isnan(rows[1, 1]) and np.isnan(rows[3, 0])
     assert np.array_equal(rows[:, 2], tau_s.astype(np.float64)) and np.array_equal(rows[:, 3], np.diff(seg).astype(np.float64))
     assert np.array_equal(rows[:, 4:], engine.aggregate_dev(t(f0), t(f1), seg_t, ctx=ctx).cpu().numpy())
+
+
+# ------------------------------------------------------------------ fused EEG window kernel
+def test_fused_eeg_window_equals_two_kernels(ctx):
+    """tda_eeg_window_batch_dev (samples -> corr -> dist -> Rips in one launch, nb2:198-207 + utils.py:135-141) against
+    tda_corr_dist_batch_dev + tda_rips_dm_batch_dev on BASELINE.json configs[1] (710 windows): rows, counts and
+    status words bit for bit, and the optional matrices equal to the corr_dist kernel's."""
+    import torch
+    dev = torch.device("cuda", ctx.device)
+    W = synth.eeg_windows(710, seed=11, windows_per_recording=15)
+    W[5, 7] = 0.5                        # zero-variance channel
+    W[6, 12] = W[6, 3]                   # duplicated channel: zero-length edge
+    wt = torch.from_numpy(W).to(dev)
+    dist = torch.empty((710, 47, 47), dtype=torch.float64, device=dev)
+    corr = torch.empty_like(dist)
+    engine.corr_dist_dev(wt, dist, corr, ctx=ctx)
+    two = engine.rips_dm_dev(dist, ctx=ctx)
+    for words in (1, 2):
+        ctx.set_class_words(words, 1)
+        try:
+            d2 = torch.full_like(dist, -1.0)
+            c2 = torch.full_like(dist, -1.0)
+            one = engine.eeg_window_dev(wt, dist_t=d2, corr_t=c2, ctx=ctx)
+            bare = engine.eeg_window_dev(wt, ctx=ctx)               # without the matrices
+        finally:
+            ctx.set_class_words(2, 1)
+        torch.cuda.synchronize()
+        assert torch.equal(d2, dist) and torch.equal(c2, corr)
+        for got in (one, bare):
+            assert torch.equal(got.c0, two.c0) and torch.equal(got.c1, two.c1) and torch.equal(got.status, two.status)
+            assert int(got.status.max()) == 0
+            k0 = int(two.c0.max()); k1 = int(two.c1.max())
+            m0 = torch.arange(47, device=dev)[None, :] < two.c0[:, None]
+            m1 = torch.arange(got.h1.shape[1], device=dev)[None, :] < two.c1[:, None]
+            assert torch.equal(got.h0[m0], two.h0[m0]) and torch.equal(got.h1[m1], two.h1[m1]) and k0 <= 47 and k1 > 0
+    # and against the oracle on a sample
+    e0, e1 = one.to_lists()
+    for w in (0, 5, 6, 349, 709):
+        _, od = port.corr_dist(W[w])
+        o = port.rips_dm(od)
+        assert _same_multiset(e0[w], o[0]) and _same_multiset(e1[w], o[1])
+
+
+def test_fused_eeg_window_widening_passes(ctx):
+    """White-noise windows need more than 64 classes at once: the first pass flags them and the widening passes of
+    the fused kernel (which recompute the matrix from the samples) deliver the same diagrams as the two-kernel path."""
+    import torch
+    dev = torch.device("cuda", ctx.device)
+    W = synth.eeg_windows(96, seed=5, kind="white")
+    wt = torch.from_numpy(W).to(dev)
+    dist = engine.corr_dist_dev(wt, ctx=ctx)
+    two = engine.rips_dm_dev(dist, ctx=ctx)
+    ctx.set_class_words(1, 1)
+    try:
+        ctx.set_retry_policy(ctx.RETRY_FIRST_PASS)
+        first = engine.eeg_window_dev(wt, ctx=ctx)
+        torch.cuda.synchronize()
+        flagged = int((first.status & 2).ne(0).sum())
+        ctx.set_retry_policy(ctx.RETRY_AUTO)
+        one = engine.eeg_window_dev(wt, ctx=ctx)
+    finally:
+        ctx.set_retry_policy(ctx.RETRY_AUTO)
+        ctx.set_class_words(2, 1)
+    torch.cuda.synchronize()
+    assert flagged > 0, "the test needs windows that overflow 64 class bits"
+    assert int(one.status.max()) == 0 and torch.equal(one.c0, two.c0) and torch.equal(one.c1, two.c1)
+    a0, a1 = one.to_lists(); b0, b1 = two.to_lists()
+    for w in range(96):
+        assert np.array_equal(a0[w], b0[w]) and np.array_equal(a1[w], b1[w])
