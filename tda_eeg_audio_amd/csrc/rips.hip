@@ -363,6 +363,32 @@ struct RipsLayout {
     int total;
 };
 
+// Guard build (make DEBUG_PTS=1): 16 sentinel bytes in front of rank, ord, aux and misc and at the end of the
+// layout, written when the ranking phase is over (it legitimately uses the space across the regions) and checked
+// after the sweep; an overwritten sentinel sets status bit TDA_WIN_LDS_GUARD.  The product build has no gaps.
+#define TDA_WIN_LDS_GUARD 0x100
+#ifdef TDA_DEBUG_PTS
+#define GUARD_BYTES 16
+__device__ __forceinline__ void guard_write(unsigned char* smem, const RipsLayout& L)
+{
+    const int offs[5] = {L.off_rank, L.off_ord, L.off_aux, L.off_misc, L.total};
+    if (threadIdx.x < 20) reinterpret_cast<u32*>(smem + offs[threadIdx.x >> 2] - GUARD_BYTES)[threadIdx.x & 3] = 0xC0FFEE00u + threadIdx.x;
+    __syncthreads();
+}
+__device__ __forceinline__ int guard_check(unsigned char* smem, const RipsLayout& L)
+{
+    __syncthreads();
+    const int offs[5] = {L.off_rank, L.off_ord, L.off_aux, L.off_misc, L.total};
+    bool bad = false;
+    if (threadIdx.x < 20) bad = reinterpret_cast<u32*>(smem + offs[threadIdx.x >> 2] - GUARD_BYTES)[threadIdx.x & 3] != 0xC0FFEE00u + threadIdx.x;
+    return __syncthreads_or(bad ? 1 : 0) ? TDA_WIN_LDS_GUARD : 0;
+}
+#else
+#define GUARD_BYTES 0
+__device__ __forceinline__ void guard_write(unsigned char*, const RipsLayout&) {}
+__device__ __forceinline__ int guard_check(unsigned char*, const RipsLayout&) { return 0; }
+#endif
+
 // misc block (byte offsets inside off_misc); the class tables at its end are sized by the variant
 #define MISC_COMP 0                                          // int comp[128] / u32 vmax[128] (before the sweep)
 #define MISC_CAND 512                                        // u64 cand[16]
@@ -1239,11 +1265,13 @@ __device__ void rips_dm_rest(unsigned char* smem, const int win, int n, float th
     const int Ev = count_effective_edges<NT>(key32, E, n, tkey, vmax, red, teff, kmin);
     rank_edges<NT, (NVW == 1 ? 2048 : 8192), true>(key32, E, teff, kmin, members, cursor, wsum, rank, ord, skey);
     PROF_MARK(1);
+    guard_write(smem, L);
     int k0, k1, st;
     KeyFromLds kf{skey};
     rips_sweep<NT, NVW, W, WT>(n, E, Ev, rank, ord, psi, misc, kf,
                        out.h0 + (size_t)win * out.h0_cap * 2, out.h0_cap,
                        out.h1 + (size_t)win * out.h1_cap * 2, out.h1_cap, k0, k1, st);
+    st |= guard_check(smem, L);
     PROF_MARK(3);
     PROF_COUNT(8, 1);
     PROF_COUNT(9, E);
@@ -1364,7 +1392,7 @@ __device__ __noinline__ void row_maxima(const u32* key32, u32* vmax, int P)
 // 64 and 128 classes: four waves per SIMD (128 VGPRs, no spills).  Five (96 VGPRs, 32 B of scratch per lane) paid while
 // the sweep spent its time at barriers; with the one-barrier votes four is 1 % faster end to end
 template <int NT, int NVW, int W, typename WT, bool RETRY>
-__global__ void __launch_bounds__(NT, (W <= 2 && !RETRY) ? 4 : 1)
+__global__ void __launch_bounds__(NT, (W <= 2 && !RETRY) ? 4 : 2)      // (never 1: see eeg_window_kernel)
 rips_dm_kernel(const double* __restrict__ dm, int n_win, int n, float thresh, int symmetrise, RipsLayout L,
                RipsOut out, unsigned long long* __restrict__ retry_ctr)
 {
@@ -1480,11 +1508,13 @@ __device__ void rips_cloud_window(unsigned char* smem, const int win, const doub
     PROF_MARK(0);
     rank_edges<NT, 8192, false>(key32, E, teff, kmin, members, cursor, wsum, rank, ord, nullptr);
     PROF_MARK(1);
+    guard_write(smem, L);
     int k0, k1, st;
     if (P <= 64)
         rips_sweep<NT, 1, W, WT>(P, E, Ev, rank, ord, psi, misc, kf, h0, out.h0_cap, h1, out.h1_cap, k0, k1, st);
     else
         rips_sweep<NT, 2, W, WT>(P, E, Ev, rank, ord, psi, misc, kf, h0, out.h0_cap, h1, out.h1_cap, k0, k1, st);
+    st |= guard_check(smem, L);
     PROF_MARK(3);
     PROF_COUNT(8, 1);
     PROF_COUNT(9, E);
@@ -1598,8 +1628,13 @@ __device__ __forceinline__ void eeg_one_window(unsigned char* smem, const double
 
 // RETRY = false: one window per workgroup and NO loop over windows -- with the loop the compiler hoists the address
 // arithmetic of the window fetch out of it and the kernel spills 141 registers (measured).
+// Launch bound: never ONE wave per SIMD.  At that bound the compiler moves values into the accumulation registers
+// (AGPRs), and the widening pass of the streaming form then delivered wrong diagrams for every window it redid
+// (deterministically; tools/dbg_fused.py) while the same source at two waves per SIMD (256 VGPRs, no AGPRs) is
+// exact -- not understood beyond that, so every variant of this kernel stays at >= 2 waves per SIMD and
+// tests/test_gpu_parity.py::test_fused_eeg_window_512_classes covers the widest one.
 template <int NB, bool RES, int W, bool RETRY>
-__global__ void __launch_bounds__(256, (W > 2 || RETRY) ? 1 : (RES ? 3 : 4))
+__global__ void __launch_bounds__(256, (W > 2 || RETRY) ? 2 : (RES ? 3 : 4))
 eeg_window_kernel(const double* __restrict__ windows, int n_win, int n_ch, int n_t, float thresh, RipsLayout L, RipsOut out,
                   double* __restrict__ dist, double* __restrict__ corr, unsigned long long* __restrict__ retry_ctr)
 {
@@ -1630,16 +1665,16 @@ static RipsLayout make_layout(int n, int psi_bytes_per_edge, int aux_bytes, int 
     // members take the place of ord, otherwise they follow the keys (rank / ord lie beyond 8E then).
     // aux (point cloud / sorted keys) and misc follow; the bucket cursors (NB u16) lie over the part of misc that
     // only the sweep uses.
-    L.off_rank = align16(psi_bytes);
-    L.off_ord = align16(L.off_rank + 2 * E);
+    L.off_rank = align16(psi_bytes) + GUARD_BYTES;
+    L.off_ord = align16(L.off_rank + 2 * E) + GUARD_BYTES;
     L.off_members = psi_bytes_per_edge < 8 ? L.off_ord : 4 * E;
-    int after_rank = align16(L.off_ord + 2 * E);
+    int after_rank = align16(L.off_ord + 2 * E) + GUARD_BYTES;
     L.off_aux = after_rank;
-    L.off_misc = align16(L.off_aux + aux_bytes);
+    L.off_misc = align16(L.off_aux + aux_bytes) + GUARD_BYTES;
     int misc_bytes = MISC_BYTES(8 * psi_bytes_per_edge);
     const int nb = (NT == 256 && n <= 64) ? 2048 : 8192;
     if (misc_bytes < MISC_SORTCNT + 2 * nb) misc_bytes = MISC_SORTCNT + 2 * nb;
-    L.total = align16(L.off_misc + misc_bytes);
+    L.total = align16(L.off_misc + misc_bytes) + GUARD_BYTES;
     return L;
 }
 

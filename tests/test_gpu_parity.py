@@ -613,3 +613,55 @@ def test_fused_eeg_window_widening_passes(ctx):
     a0, a1 = one.to_lists(); b0, b1 = two.to_lists()
     for w in range(96):
         assert np.array_equal(a0[w], b0[w]) and np.array_equal(a1[w], b1[w])
+
+
+def _bipartite_windows(n_rep, seed):
+    """47-channel windows whose correlation graph is K(23,24): every cross-group correlation 0.23, every
+    within-group one 0.20 (a positive-definite Gram matrix), so the 552 cross edges (d = 1.241) enter before any
+    within-group edge (d = 1.265) and (23-1)(24-1) = 506 H1 classes are alive at once -- the theoretical maximum
+    for 47 points, which only the 512-bit widening pass can hold."""
+    rng = np.random.default_rng(seed)
+    m, n, c, w = 23, 24, 0.23, 0.20
+    G = np.full((47, 47), w)
+    G[:m, m:] = c; G[m:, :m] = c
+    np.fill_diagonal(G, 1.0)
+    ev, U = np.linalg.eigh(G)
+    assert ev.min() > 0
+    L = (U * np.sqrt(ev)) @ U.T
+    out = np.empty((n_rep, 47, 250))
+    for k in range(n_rep):
+        Z = rng.standard_normal((250, 47))
+        Z -= Z.mean(axis=0)
+        Q, _ = np.linalg.qr(Z)
+        out[k] = (L @ Q.T) * rng.uniform(0.5, 2.0, size=(47, 1))      # per-channel scale: correlation unchanged
+    return out
+
+
+def test_fused_eeg_window_512_classes(ctx):
+    """The widest widening pass of the fused kernel (512 class bits, 256 VGPRs) on windows that need 506 classes
+    alive at once, against the two-kernel path and the oracle."""
+    import torch
+    dev = torch.device("cuda", ctx.device)
+    W = _bipartite_windows(5, seed=3)
+    W = np.concatenate([W, synth.eeg_windows(7, seed=2)])             # ordinary windows in the same batch
+    wt = torch.from_numpy(W).to(dev)
+    dist = engine.corr_dist_dev(wt, ctx=ctx)
+    two = engine.rips_dm_dev(dist, h1_cap=1024, ctx=ctx)
+    ctx.set_retry_policy(ctx.RETRY_FIRST_PASS)
+    try:
+        first = engine.eeg_window_dev(wt, h1_cap=1024, ctx=ctx)
+        torch.cuda.synchronize()
+        assert (first.status[:5] & 2).ne(0).all() and (first.status[5:] == 0).all()
+    finally:
+        ctx.set_retry_policy(ctx.RETRY_AUTO)
+    one = engine.eeg_window_dev(wt, h1_cap=1024, ctx=ctx)
+    torch.cuda.synchronize()
+    assert int(one.status.max()) == 0 and int(two.status.max()) == 0
+    assert torch.equal(one.c0, two.c0) and torch.equal(one.c1, two.c1)
+    a0, a1 = one.to_lists(); b0, b1 = two.to_lists()
+    d = dist.cpu().numpy()
+    for w in range(len(W)):
+        assert np.array_equal(a0[w], b0[w]) and np.array_equal(a1[w], b1[w])
+        o = port.rips_dm(d[w])
+        assert _same_multiset(a0[w], o[0]) and _same_multiset(a1[w], o[1])
+    assert min(len(a1[w]) for w in range(5)) >= 400              # hundreds of classes born before the first death
