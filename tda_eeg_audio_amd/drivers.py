@@ -10,9 +10,12 @@ reference's on-disk formats.
   process_file_features   scripts/tda_eeg_classification_v2.py:338-442  (220 features / recording)
   get_eeg_diagrams        scripts/matched_vs_mismatched.py:66-85
   get_audio_diagrams_from_windows / compute_cross_wasserstein   mvm:43-63, 87-95
-  process_recording_arrays  scripts/tda_eeg_audio_comparison.py:63-122 given the band-passed audio
-                            windows (the .mat loading / envelope / filtering in front, cmp:53-65, is
-                            host-side preparation outside this engine)
+  process_recording_arrays  scripts/tda_eeg_audio_comparison.py:63-122 given the band-passed audio windows
+  process_recording / process_recording_file / run_analysis / detailed_rows
+                            cmp:45-157 from the raw audio track (.mat) and the graphs/ tree to the rows of
+                            results/eeg_audio_tda_detailed.csv
+  validate_distance_matrix  scripts/tda_eeg_classification_v2.py:110-140 (first window of every band, v2:380-382)
+  save_dataset              v2:670-688 incl. features/metadata.csv / metadata.json
 """
 import hashlib
 from pathlib import Path
@@ -38,6 +41,49 @@ def select_windows_md5(dirname, band, n_windows, max_n, random_state=42):
     return np.random.default_rng(seed).choice(n_windows, size=max_n, replace=False)
 
 
+def check_status(st, what, allow_degenerate=False):
+    """Raises on any window status the drivers cannot publish: class overflow beyond the widest pass (2), H1 rows
+    cut at h1_cap (1), a cloud with more than TDA_MAX_POINTS points (16).  The reference has no such limits (ripser
+    grows its columns on the heap), so silently passing a cut diagram on would be a different answer."""
+    st = np.asarray(st)
+    bad = st & (1 | 2 | 16)
+    if not allow_degenerate:
+        bad = bad | (st & 4)
+    if bad.any():
+        w = int(np.nonzero(bad)[0][0])
+        raise RuntimeError(f"{what}: window {w} reported status {int(st[w])} "
+                           "(1: H1 rows cut at h1_cap, 2: class capacity exceeded, 16: cloud too large)")
+
+
+def validate_distance_matrix(distance_matrix, name=""):
+    """scripts/tda_eeg_classification_v2.py:110-140 -- (is_valid, issues) with the reference's checks, order and
+    messages: 2-D, square, symmetric (rtol 1e-5, atol 1e-8), no value below -1e-10, zero diagonal (atol 1e-10), no
+    NaN, no Inf.  The reference runs it on the FIRST window of every band only (v2:380) and only logs the outcome
+    into the recording's metadata (v2:381-382): a host-side check of one 47 x 47 matrix per recording-band."""
+    distance_matrix = np.asarray(distance_matrix)
+    issues = []
+    if distance_matrix.ndim != 2:
+        issues.append(f"No es 2D: forma={distance_matrix.shape}")
+        return False, issues
+    n, m = distance_matrix.shape
+    if n != m:
+        issues.append(f"No es cuadrada: forma=({n}, {m})")
+        return False, issues
+    if not np.allclose(distance_matrix, distance_matrix.T, rtol=1e-5, atol=1e-8):
+        max_diff = np.max(np.abs(distance_matrix - distance_matrix.T))
+        issues.append(f"No simétrica: asimetría máxima={max_diff:.6f}")
+    if np.any(distance_matrix < -1e-10):
+        issues.append(f"Valores negativos presentes: min={np.min(distance_matrix):.6f}")
+    diag = np.diag(distance_matrix)
+    if not np.allclose(diag, 0, atol=1e-10):
+        issues.append(f"Diagonal no cero: max={np.max(np.abs(diag)):.6f}")
+    if np.any(np.isnan(distance_matrix)):
+        issues.append("Contiene valores NaN")
+    if np.any(np.isinf(distance_matrix)):
+        issues.append("Contiene valores Inf")
+    return len(issues) == 0, issues
+
+
 def feature_names(bands=BANDS):
     """Column order of features/feature_names.txt (v2:429-436)."""
     names = []
@@ -54,8 +100,9 @@ def features_from_distances(dist_list, thresh=MAX_EDGE_LENGTH):
     sizes = np.array([len(d) for d in dist_list])
     allw = np.concatenate([np.asarray(d, dtype=np.float64) for d in dist_list if len(d)], axis=0)
     h0, c0, h1, c1, st = engine.rips_dm_batch(allw, thresh=thresh, raw=True)
-    if (st & 2).any():
-        raise RuntimeError("H1 class capacity exceeded")
+    if (st & 1).any():                         # more H1 rows than the default capacity: once more, large enough
+        h0, c0, h1, c1, st = engine.rips_dm_batch(allw, thresh=thresh, raw=True, h1_cap=int(c1.max()))
+    check_status(st, "features_from_distances")
     f0 = engine.features_batch(h0, c0)
     f1 = engine.features_batch(h1, c1)
     seg = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int32)
@@ -83,6 +130,9 @@ def process_file_features(file_dir, freq_bands=BANDS, max_dim=1, max_edge_length
         metadata["n_windows"][band] = n_windows
         if n_windows == 0:
             continue
+        is_valid, issues = validate_distance_matrix(dms[0], f"{band}[0]")             # v2:380-382
+        if not is_valid:
+            metadata["validation_issues"].extend([f"{band}: {i}" for i in issues])
         if max_windows_per_band is None:
             use = np.arange(n_windows)
         else:
@@ -123,6 +173,7 @@ def get_eeg_diagrams(graph_dir, bands=BANDS):
             continue
         idx = select_windows_even(dms.shape[0])
         h0, h1, st = engine.rips_dm_batch(dms[idx])
+        check_status(st, f"get_eeg_diagrams({bname})")
         result[bname] = [[a, b] for a, b in zip(h0, h1)]
     return result
 
@@ -137,6 +188,7 @@ def get_audio_diagrams_from_windows(audio_wins):
     sel = np.asarray(audio_wins, dtype=np.float64)[idx]
     tau = int(engine.tau_batch(sel[:1], max_lag=sel.shape[1] // 2)[0])
     h0, h1, npts, st = engine.takens_rips_batch(sel, tau, TAKENS_DIM, TAKENS_SUBSAMPLE)
+    check_status(st, "get_audio_diagrams", allow_degenerate=True)
     return [[a, b] for a, b, p in zip(h0, h1, npts) if p >= 3]
 
 
@@ -169,10 +221,12 @@ def process_recording_arrays(audio_band_windows, eeg_dists_by_band):
         idx = select_windows_even(n_win)
         tau = int(engine.tau_batch(aw[idx[:1]], max_lag=aw.shape[1] // 2)[0])          # cmp:83
         a0, ac0, a1, ac1, npts, ast = engine.takens_rips_batch(aw[idx], tau, TAKENS_DIM, TAKENS_SUBSAMPLE, raw=True)
+        check_status(ast, f"process_recording({bname}) audio", allow_degenerate=True)
         keep = npts >= 3                                                               # cmp:90-91
         if not keep.any():
             continue
         e0, ec0, e1, ec1, est = engine.rips_dm_batch(ed[idx], raw=True)
+        check_status(est, f"process_recording({bname}) eeg")
         k = np.nonzero(keep)[0].astype(np.int32)
         w0, s0 = engine.wasserstein_batch(e0, ec0, a0, ac0, k, k, want_status=True)
         w1, s1 = engine.wasserstein_batch(e1, ec1, a1, ac1, k, k, want_status=True)
@@ -272,6 +326,9 @@ def create_dataset(graphs_dir_slow, graphs_dir_fast, freq_bands=BANDS, max_dim=1
             md["n_windows"][band] = n_windows
             if n_windows == 0:
                 continue
+            is_valid, issues = validate_distance_matrix(dms[0], f"{band}[0]")           # v2:380-382
+            if not is_valid:
+                md["validation_issues"].extend([f"{band}: {i}" for i in issues])
             if max_windows_per_band is None:
                 use = np.arange(n_windows)
             else:
@@ -293,16 +350,30 @@ def create_dataset(graphs_dir_slow, graphs_dir_fast, freq_bands=BANDS, max_dim=1
             X[i, 44 * bi:44 * (bi + 1)] = agg[g]
     if world_size > 1:
         import torch
-        local = torch.from_numpy(X[mine])
-        X = gather(local, mine, shards, n_rec).numpy()
+        import torch.distributed as tdist_
+        from . import dist as tdist
+        gather = gather or tdist.all_gather_rows
+        # the rows travel from this rank's GPU (RCCL moves device memory; gloo, in the rehearsals, is staged
+        # through the host by all_gather_rows itself) and come back to the host once assembled
+        dev = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu")
+        X = gather(torch.from_numpy(X[mine]).to(dev), mine, shards, n_rec).cpu().numpy()
+        if tdist_.is_initialized():              # the per-recording metadata of the other ranks (v2:684-688 saves all)
+            parts = [None] * world_size
+            tdist_.all_gather_object(parts, [(int(i), metadata[i]) for i in mine])
+            for part in parts:
+                for i, md in part:
+                    metadata[i] = md
     y = np.array([lab for _, lab in entries])
     filenames = [d.name for d, _ in entries]
     subjects = np.array([f.split("_")[0] for f in filenames])
     return X, y, subjects, names, filenames, [m for m in metadata if m is not None]
 
 
-def save_dataset(features_dir, X, y, subjects, names, filenames):
-    """v2:670-682 -- features/X.npy, y.npy, subjects.npy, feature_names.txt, filenames.txt."""
+def save_dataset(features_dir, X, y, subjects, names, filenames, metadata=None):
+    """v2:670-688 -- features/X.npy, y.npy, subjects.npy, feature_names.txt, filenames.txt and, when the
+    per-recording metadata are given, metadata.csv (pandas.DataFrame(all_metadata).to_csv(index=False)) and
+    metadata.json (indent 2, ensure_ascii False)."""
+    import json
     features_dir = Path(features_dir)
     features_dir.mkdir(exist_ok=True, parents=True)
     np.save(features_dir / "X.npy", X)
@@ -310,6 +381,75 @@ def save_dataset(features_dir, X, y, subjects, names, filenames):
     np.save(features_dir / "subjects.npy", subjects)
     (features_dir / "feature_names.txt").write_text("".join(f"{n}\n" for n in names))
     (features_dir / "filenames.txt").write_text("".join(f"{n}\n" for n in filenames))
+    if metadata:
+        import pandas as pd
+        pd.DataFrame(metadata).to_csv(features_dir / "metadata.csv", index=False)
+        with open(features_dir / "metadata.json", "w") as f:
+            json.dump(metadata, f, indent=2, ensure_ascii=False)
+
+
+DETAILED_COLUMNS = ["filename", "condition", "subject", "band", "wasserstein_h0", "wasserstein_h1", "n_windows", "tau"] + \
+    [f"corr_{feat}_{k}" for feat in engine.SPEARMAN_FEATURES for k in ("r", "p")]
+
+
+def process_recording_file(filename, condition, data_dir, graphs_dir, fs_audio=44100):
+    """cmp:45-124 on the reference's directory layout: data/<condition>/<filename>.mat (audio track `y`, averaged
+    over its channels as load_audio does, utils.py:47-53) and graphs/<condition>/<stem>/<band>_distances.npy.
+    Returns the reference's result dict {"filename", "condition", "subject", "bands": {...}} or None when a path is
+    missing or no band survives (cmp:48-49, cmp:124)."""
+    mat_path = Path(data_dir) / condition / filename
+    graph_dir = Path(graphs_dir) / condition / filename.replace(".mat", "")
+    if not mat_path.exists() or not graph_dir.exists():
+        return None
+    import scipy.io as sio
+    y = sio.loadmat(str(mat_path))["y"]
+    if y.ndim == 2:
+        y = y.mean(axis=1)
+    dists = {}
+    for bname in BANDS:
+        f = graph_dir / f"{bname}_distances.npy"
+        if f.exists():                                                   # cmp:67-70
+            dists[bname] = np.load(str(f))
+    bands = process_recording(y.astype(np.float64), dists, fs_audio)
+    for bd in bands.values():                                            # the reference keeps scalars only (cmp:116-122)
+        bd.pop("audio_h1_features", None); bd.pop("eeg_h1_features", None)
+    if not bands:
+        return None
+    return {"filename": filename, "condition": condition, "subject": filename.split("_")[0], "bands": bands}
+
+
+def detailed_rows(all_results):
+    """cmp:145-157 -- one row per (recording, band): the columns of results/eeg_audio_tda_detailed.csv."""
+    rows = []
+    for r in all_results:
+        for bname, bd in r["bands"].items():
+            row = {"filename": r["filename"], "condition": r["condition"], "subject": r["subject"], "band": bname,
+                   "wasserstein_h0": bd["wasserstein_h0"], "wasserstein_h1": bd["wasserstein_h1"],
+                   "n_windows": bd["n_windows"], "tau": bd["tau"]}
+            for feat, vals in bd["feature_correlations"].items():
+                row[f"corr_{feat}_r"] = vals["r"]
+                row[f"corr_{feat}_p"] = vals["p"]
+            rows.append(row)
+    return rows
+
+
+def run_analysis(data_dir, graphs_dir, out_csv=None, conditions=("slow", "fast")):
+    """cmp:126-157, the per-recording half: every data/<condition>/*.mat in sorted order through
+    process_recording_file, then the detailed table (written as results/eeg_audio_tda_detailed.csv when out_csv is
+    given).  The statistics and plots behind it (cmp:159-349) are outside this engine."""
+    import pandas as pd
+    all_results = []
+    for condition in conditions:
+        d = Path(data_dir) / condition
+        for fn in sorted(f.name for f in d.glob("*.mat")) if d.exists() else []:
+            r = process_recording_file(fn, condition, data_dir, graphs_dir)
+            if r:
+                all_results.append(r)
+    df = pd.DataFrame(detailed_rows(all_results), columns=DETAILED_COLUMNS)
+    if out_csv:
+        Path(out_csv).parent.mkdir(parents=True, exist_ok=True)
+        df.to_csv(out_csv, index=False)
+    return all_results, df
 
 
 def process_recording(audio, eeg_dists_by_band, fs_audio=44100):

@@ -133,3 +133,70 @@ def test_all_gather_rows_gloo(world, tmp_path):
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=240, env=env)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "GATHER_OK" in r.stdout
+
+
+def test_validate_distance_matrix_matches_reference():
+    """drivers.validate_distance_matrix against the answers of the reference's own function
+    (scripts/tda_eeg_classification_v2.py:110-140; fixture made by tests/golden/make_golden_drivers.py)."""
+    import json
+    from tda_eeg_audio_amd import drivers
+    g = np.load(os.path.join(ROOT, "tests", "golden", "reference_golden_drivers.npz"))
+    answers = json.loads(str(g["vdm_answers"]))
+    assert len(answers) == 11
+    with np.errstate(all="ignore"):
+        for k, exp in answers.items():
+            ok, issues = drivers.validate_distance_matrix(g[f"vdm_{k}"], k)
+            assert ok == exp["valid"] and issues == exp["issues"], (k, issues, exp)
+
+
+def test_detailed_rows_have_the_reference_csv_columns():
+    """cmp:145-157: the header of the reference's results/eeg_audio_tda_detailed.csv (repeated here as data)."""
+    from tda_eeg_audio_amd import drivers, engine
+    header = ("filename,condition,subject,band,wasserstein_h0,wasserstein_h1,n_windows,tau,corr_mean_persistence_r,"
+              "corr_mean_persistence_p,corr_total_persistence_r,corr_total_persistence_p,corr_persistence_entropy_r,"
+              "corr_persistence_entropy_p,corr_max_persistence_r,corr_max_persistence_p,corr_n_features_r,corr_n_features_p")
+    assert drivers.DETAILED_COLUMNS == header.split(",")
+    res = [{"filename": "bb01_ut01.mat", "condition": "slow", "subject": "bb01", "bands": {
+        "delta": {"wasserstein_h0": 13.25, "wasserstein_h1": 0.81, "n_windows": 15, "tau": 84,
+                  "feature_correlations": {f: {"r": 0.1 * i, "p": 0.5} for i, f in enumerate(engine.SPEARMAN_FEATURES)}}}}]
+    rows = drivers.detailed_rows(res)
+    assert len(rows) == 1 and list(rows[0]) == drivers.DETAILED_COLUMNS
+    assert rows[0]["corr_n_features_r"] == pytest.approx(0.4) and rows[0]["tau"] == 84
+
+
+def test_oracle_segment_step_equals_python_restatement():
+    """orc_segment_step (the C unit bench.py's cpu_baseline times) == oracle/pipeline_ref.py, incl. a group whose
+    Takens clouds have fewer than 3 points: its windows leave the distances (cmp:90-91), the band gets NaN."""
+    from oracle import pipeline_ref, port
+    from tda_eeg_audio_amd import synth
+    eeg = synth.eeg_windows(10, seed=3, windows_per_recording=5)
+    aud = synth.audio_windows(10, "theta", seed=5)
+    t = np.arange(250) / 250.0
+    aud[5:] = 1.0 - t[None, :] * 0.5                    # slow ramp: no zero crossing of the autocorrelation below lag 125
+    ref = pipeline_ref.reference_step_cpu(eeg, aud, [0, 5, 10])
+    rows = np.stack([port.segment_step(eeg[:5], aud[:5]), port.segment_step(eeg[5:], aud[5:])])
+    assert np.array_equal(ref, rows, equal_nan=True)
+    assert ref[1, 2] > 60 and np.isfinite(ref[1, :2]).all()       # a long delay, small clouds, still >= 3 points
+    # tau = 124 -> P = 1 < 3: every window skipped, distances NaN, features still aggregated
+    port_tau = port.compute_tau
+    try:
+        port.compute_tau = lambda s, max_lag=None: 124
+        r = pipeline_ref.reference_step_cpu(eeg[:5], aud[:5], [0, 5])
+    finally:
+        port.compute_tau = port_tau
+    assert np.isnan(r[0, :2]).all() and r[0, 2] == 124 and np.isfinite(r[0, 4:]).all()
+
+
+def test_bench_launch_contract_without_gpu():
+    """bench.py --gpus N: WORLD_SIZE != N is an error (exit 2), and a plain `--gpus 2` on a box with fewer GPUs
+    refuses before starting any rank -- it never silently measures one GPU."""
+    import torch
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--no-cpu"], env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 2 and "WORLD_SIZE=1 but --gpus 2" in r.stderr
+    if torch.cuda.device_count() < 2:
+        env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--no-cpu"], env=env,
+                           capture_output=True, text=True, timeout=300)
+        assert r.returncode == 2 and "GPU(s) visible" in r.stderr

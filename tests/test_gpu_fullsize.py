@@ -159,3 +159,24 @@ def test_config4_audio_and_config5_pairs(ctx):
     dac, _ = engine.wasserstein_dev(eeg.h1, eeg.c1, eeg.h1, eeg.c1, t[:, 0].contiguous(), t[:, 2].contiguous(), ctx=ctx)
     torch.cuda.synchronize()
     assert bool((dac <= dab + dbc + 1e-9).all())
+
+
+def test_bench_two_rank_rehearsal_and_corpus_rows(tmp_path):
+    """`python bench.py --gpus 2` starts its two ranks itself (here both on the one GPU of the box, all-gather over
+    gloo: --share-gpu): recordings dealt by dist.shard_recordings, one all-gather of the (n_rec, 5 x 48) rows per
+    pass, ONE JSON line from rank 0 with n_gpus = 2 and strong scaling over the same fixed corpus."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--share-gpu", "--recordings", "36", "--steps", "2",
+           "--warmup", "1", "--no-cpu", "--features-steps", "1"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["value"] > 0 and d["unit"] == "windows/s"
+    assert d["config"]["windows_per_pass"] == 36 * 5 * 15 and d["config"]["windows_per_gpu_per_pass"] == 18 * 5 * 15
+    assert d["config"]["result_rows_finite_frac"] == 1.0
+    assert d["features_pass"]["matrix_shape"] == [36, 220] and d["features_pass"]["matrix_finite"]
+    assert d["roofline"]["frac"] > 0 and d["roofline"]["bound"] == "hbm"

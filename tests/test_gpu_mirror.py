@@ -1,5 +1,7 @@
 """GPU tests of the reference-named mirrors (tda_eeg_audio_amd.utils / graphs / drivers): same
 call shapes as scripts/utils.py and nb2, results checked against the oracle and the golden vectors."""
+import os
+
 import numpy as np
 import pytest
 
@@ -159,3 +161,102 @@ def test_spearman_matches_scipy(ctx):
             else:
                 rr, pp = 0.0, 1.0
             assert abs(r[s, k] - rr) < 1e-12 and abs(p[s, k] - pp) < 1e-10, (s, k, r[s, k], rr, p[s, k], pp)
+
+
+def test_process_recording_file_and_detailed_csv(ctx, tmp_path):
+    """cmp:45-157 on the reference's layout: data/<cond>/<rec>.mat (audio track `y`) + graphs/<cond>/<rec>/ ->
+    the rows of eeg_audio_tda_detailed.csv; values against process_recording_arrays on the same inputs."""
+    import scipy.io as sio
+    from tda_eeg_audio_amd import preprocess
+    rng = np.random.default_rng(11)
+    recs = [("slow", "bb01_ut01"), ("fast", "bb02_ut04")]
+    for cond, name in recs:
+        (tmp_path / "data" / cond).mkdir(parents=True, exist_ok=True)
+        n = int(44100 * 4.2)
+        t = np.arange(n) / 44100.0
+        y = (np.sin(2 * np.pi * 3.1 * t) + 0.5 * rng.standard_normal(n)) * (1 + 0.5 * np.sin(2 * np.pi * 0.7 * t))
+        sio.savemat(str(tmp_path / "data" / cond / f"{name}.mat"), {"y": np.stack([y, y * 0.5], axis=1)})   # stereo
+        d = tmp_path / "graphs" / cond / name
+        d.mkdir(parents=True)
+        for bi, band in enumerate(drivers.BANDS[:3]):                  # two bands have no graph file (cmp:67-69)
+            np.save(d / f"{band}_distances.npy", port.corr_dist_batch(synth.eeg_windows(14 + bi, seed=bi + len(name)))[1])
+    (tmp_path / "data" / "slow" / "orphan.mat").write_bytes(b"")          # no graph dir: skipped (cmp:48-49)
+    results, df = drivers.run_analysis(tmp_path / "data", tmp_path / "graphs", out_csv=tmp_path / "results" / "detailed.csv")
+    assert [r["filename"] for r in results] == ["bb01_ut01.mat", "bb02_ut04.mat"]
+    assert list(df.columns) == drivers.DETAILED_COLUMNS and len(df) == 6
+    assert list(df["band"][:3]) == drivers.BANDS[:3] and set(df["n_windows"]) <= {13, 14, 15}
+    assert (tmp_path / "results" / "detailed.csv").read_text().splitlines()[0] == ",".join(drivers.DETAILED_COLUMNS)
+    # same numbers as the array-level driver on the same audio
+    y = sio.loadmat(str(tmp_path / "data" / "slow" / "bb01_ut01.mat"))["y"].mean(axis=1)
+    aw = preprocess.audio_to_band_windows(y.astype(np.float64), 44100)
+    dists = {b: np.load(tmp_path / "graphs" / "slow" / "bb01_ut01" / f"{b}_distances.npy") for b in drivers.BANDS[:3]}
+    direct = drivers.process_recording_arrays(aw, dists)
+    for b in drivers.BANDS[:3]:
+        row = df[(df.filename == "bb01_ut01.mat") & (df.band == b)].iloc[0]
+        assert row.wasserstein_h0 == direct[b]["wasserstein_h0"] and row.tau == direct[b]["tau"]
+        assert np.isfinite(row.wasserstein_h1) and 0.0 <= row.corr_n_features_p <= 1.0
+
+
+def test_validation_issues_reach_the_metadata_files(ctx, tmp_path):
+    """v2:380-382 + v2:684-688: the first window of a band is validated, the outcome lands in the recording's
+    metadata, and save_dataset writes metadata.csv / metadata.json next to X.npy."""
+    import json
+    for cond, name in (("slow", "bb01_ut01"), ("fast", "bb01_ut02")):
+        d = tmp_path / "graphs" / cond / name
+        d.mkdir(parents=True)
+        for band in drivers.BANDS:
+            dm = port.corr_dist_batch(synth.eeg_windows(8, seed=len(band)))[1]
+            if (cond, band) == ("fast", "theta"):
+                dm[0, 3, 3] = 0.25                         # non-zero diagonal in the first window
+                dm[0, 2, 5] += 1e-3                        # and an asymmetry
+            np.save(d / f"{band}_distances.npy", dm)
+    feats, md = drivers.process_file_features(tmp_path / "graphs" / "fast" / "bb01_ut02")
+    assert md["validation_issues"] == ["theta: No simétrica: asimetría máxima=0.001000", "theta: Diagonal no cero: max=0.250000"]
+    X, y, subjects, names, filenames, meta = drivers.create_dataset(tmp_path / "graphs" / "slow", tmp_path / "graphs" / "fast")
+    assert meta[0]["validation_issues"] == [] and meta[1]["validation_issues"] == md["validation_issues"]
+    drivers.save_dataset(tmp_path / "features", X, y, subjects, names, filenames, meta)
+    saved = json.load(open(tmp_path / "features" / "metadata.json"))
+    assert saved[1]["validation_issues"] == md["validation_issues"] and saved[0]["filename"] == "bb01_ut01"
+    head = (tmp_path / "features" / "metadata.csv").read_text().splitlines()[0].split(",")
+    assert head[:3] == ["n_windows", "n_windows_used", "validation_issues"] and "filename" in head and "label" in head
+
+
+_DS_WORKER = r"""
+import os, sys
+sys.path.insert(0, sys.argv[1])
+import numpy as np, torch, torch.distributed as dist
+from tda_eeg_audio_amd import drivers
+from tda_eeg_audio_amd import dist as tdist
+rank, world, local = tdist.init_from_env(backend="gloo")       # two ranks share the one GPU of the test box
+torch.cuda.set_device(0)
+root = sys.argv[2]
+X, y, subjects, names, filenames, meta = drivers.create_dataset(root + "/graphs/slow", root + "/graphs/fast",
+                                                                rank=rank, world_size=world)
+ref = np.load(root + "/X_single.npy")
+assert np.array_equal(X, ref), np.abs(X - ref).max()
+assert [m["filename"] for m in meta] == filenames and len(meta) == len(filenames) == 5
+if rank == 0: print("DATASET_OK")
+dist.destroy_process_group()
+"""
+
+
+def test_create_dataset_two_ranks_equals_one(ctx, tmp_path):
+    """The multi-GPU replacement of the BATCH_START/BATCH_END partial files (v2:55-60, 608-638): recordings dealt
+    over two ranks, rows all-gathered from device memory, metadata of every rank collected -- identical to the
+    single-process result.  (gloo here: both ranks use the one GPU of the test box; RCCL is the driver's 8-GPU run.)"""
+    import subprocess, sys
+    for cond, names_ in (("slow", ["bb01_ut01", "bb02_ut01", "bb03_ut01"]), ("fast", ["bb01_ut02", "bb02_ut02"])):
+        for k, name in enumerate(names_):
+            d = tmp_path / "graphs" / cond / name
+            d.mkdir(parents=True)
+            for bi, band in enumerate(drivers.BANDS):
+                np.save(d / f"{band}_distances.npy", port.corr_dist_batch(synth.eeg_windows(9 + k + bi, seed=17 * k + bi))[1])
+    X = drivers.create_dataset(tmp_path / "graphs" / "slow", tmp_path / "graphs" / "fast")[0]
+    np.save(tmp_path / "X_single.npy", X)
+    script = tmp_path / "worker.py"
+    script.write_text(_DS_WORKER)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", str(29700 + os.getpid() % 200), str(script), root, str(tmp_path)]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=dict(os.environ, OMP_NUM_THREADS="1"))
+    assert r.returncode == 0 and "DATASET_OK" in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]

@@ -665,3 +665,37 @@ def test_fused_eeg_window_512_classes(ctx):
         o = port.rips_dm(d[w])
         assert _same_multiset(a0[w], o[0]) and _same_multiset(a1[w], o[1])
     assert min(len(a1[w]) for w in range(5)) >= 400              # hundreds of classes born before the first death
+
+
+def test_recording_rows_skip_degenerate_audio_windows(ctx):
+    """cmp:90-91: windows whose Takens cloud has fewer than 3 points (status bit 4) or none (16) take no part in the
+    distances; np.nanmean runs over the survivors in their order (cmp:117-118), NaN when none is left (the reference
+    drops the band, cmp:101-102).  recording_rows_kernel against numpy on crafted status words."""
+    import torch
+    dev = torch.device("cuda", ctx.device)
+    rng = np.random.default_rng(3)
+    seg = np.array([0, 15, 30, 45, 52], np.int32)
+    n = 52
+    w0 = rng.random(n) * 20; w1 = rng.random(n)
+    w1[3] = np.nan; w0[20] = np.nan                      # failed solves stay NaN and are ignored by nanmean
+    stb = np.zeros(n, np.int32)
+    stb[[1, 4, 16, 17, 18]] = 4                           # a few short clouds
+    stb[30:45] = 4                                        # a whole group: tau = 124
+    stb[47] = 16
+    f0 = rng.random((n, 11)); f1 = rng.random((n, 11))
+    tau = np.array([3, 84, 124, 7], np.int32)
+    t = lambda a: torch.from_numpy(a).to(dev)
+    out = engine.recording_rows_dev(t(w0), t(w1), t(tau), t(f0), t(f1), t(seg), status_a=t(np.zeros(n, np.int32)),
+                                    status_b=t(stb), seg_flags=torch.zeros(4, dtype=torch.int32, device=dev), ctx=ctx)
+    got = out.cpu().numpy()
+    for s in range(4):
+        a, b = seg[s], seg[s + 1]
+        keep = (stb[a:b] & (4 | 16)) == 0
+        for col, w in ((0, w0), (1, w1)):
+            x = w[a:b][keep]
+            exp = np.nanmean(x) if np.isfinite(x).any() else np.nan
+            assert (np.isnan(exp) and np.isnan(got[s, col])) or got[s, col] == exp, (s, col, got[s, col], exp)
+        assert got[s, 2] == tau[s] and got[s, 3] == b - a
+        for f in range(11):                     # v2:429-436: np.mean / np.std of the list of per-window values
+            assert got[s, 4 + 4 * f] == np.mean(list(f0[a:b, f])) and got[s, 7 + 4 * f] == np.std(list(f1[a:b, f]))
+    assert np.isnan(got[2, :2]).all()

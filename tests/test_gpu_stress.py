@@ -27,7 +27,7 @@ def stress(ctx):
 def test_stress_audio_windows_all_bands(stress, ctx, words):
     ctx.set_class_words(*words)
     try:
-        stress.audio(n_per_band=60)
+        stress.audio(n_per_band=150)
     finally:
         ctx.set_class_words(2, 1)
 
@@ -36,7 +36,7 @@ def test_stress_audio_windows_all_bands(stress, ctx, words):
 def test_stress_matrices_thresholds_and_fused_kernel(stress, ctx, words):
     ctx.set_class_words(*words)
     try:
-        stress.matrices(n=60)
+        stress.matrices(n=120)
     finally:
         ctx.set_class_words(2, 1)
 
@@ -45,14 +45,14 @@ def test_stress_matrices_thresholds_and_fused_kernel(stress, ctx, words):
 def test_stress_tie_heavy_metrics_and_small_clouds(stress, ctx, words):
     ctx.set_class_words(*words)
     try:
-        stress.ties(reps=3)
-        stress.clouds(small=6, large=3)
+        stress.ties(reps=6)
+        stress.clouds(small=12, large=6)
     finally:
         ctx.set_class_words(2, 1)
 
 
 def test_stress_wasserstein_quantised(stress):
-    stress.wasserstein(rounds=2)
+    stress.wasserstein(rounds=4)
 
 
 def test_lds_guard_build_clean():
