@@ -105,23 +105,27 @@ __device__ __forceinline__ double uni_f64(double v, int lane)
 __device__ __forceinline__ double wave_min_f64_dpp(double v) { TDA_DPP_REDUCE_F64(v, TDA_MIN_); return uni_f64(v, 63); }
 __device__ __forceinline__ double wave_max_f64_dpp(double v) { TDA_DPP_REDUCE_F64(v, TDA_MAX_); return uni_f64(v, 63); }
 
+// The DPP modifier sits on the min / max instruction itself (one instruction per step; the builtin route costs a
+// v_mov_b32_dpp plus the operation).  s_nop 1 = the two wait states between a VALU write and a DPP read of a VGPR.
+#define TDA_DPP_STEPS_(OP)                                                                   \
+    "s_nop 1\n\t" OP " %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"        \
+    "s_nop 1\n\t" OP " %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"        \
+    "s_nop 1\n\t" OP " %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"            \
+    "s_nop 1\n\t" OP " %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\t"                 \
+    "s_nop 1\n\t" OP " %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"               \
+    "s_nop 1\n\t" OP " %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"               \
+    "s_nop 1"
 __device__ __forceinline__ int wave_max_i32_dpp(int v)
 {
-#define TDA_DPP_I32_(CTRL, RM) { const int o__ = __builtin_amdgcn_update_dpp(v, v, CTRL, RM, 0xF, false); v = o__ > v ? o__ : v; }
-    TDA_DPP_I32_(0xB1, 0xF) TDA_DPP_I32_(0x4E, 0xF) TDA_DPP_I32_(0x141, 0xF) TDA_DPP_I32_(0x140, 0xF)
-    TDA_DPP_I32_(0x142, 0xA) TDA_DPP_I32_(0x143, 0xC)
-#undef TDA_DPP_I32_
+    asm volatile(TDA_DPP_STEPS_("v_max_i32_dpp") : "+v"(v));
     return __builtin_amdgcn_readlane(v, 63);
 }
 
 __device__ __forceinline__ u32 wave_min_u32_dpp(u32 x)
 {
-    int v = (int)(x ^ 0x80000000u);          // unsigned order as signed
-#define TDA_DPP_I32_(CTRL, RM) { const int o__ = __builtin_amdgcn_update_dpp(v, v, CTRL, RM, 0xF, false); v = o__ < v ? o__ : v; }
-    TDA_DPP_I32_(0xB1, 0xF) TDA_DPP_I32_(0x4E, 0xF) TDA_DPP_I32_(0x141, 0xF) TDA_DPP_I32_(0x140, 0xF)
-    TDA_DPP_I32_(0x142, 0xA) TDA_DPP_I32_(0x143, 0xC)
-#undef TDA_DPP_I32_
-    return (u32)__builtin_amdgcn_readlane(v, 63) ^ 0x80000000u;
+    int v = (int)x;
+    asm volatile(TDA_DPP_STEPS_("v_min_u32_dpp") : "+v"(v));
+    return (u32)__builtin_amdgcn_readlane(v, 63);
 }
 
 // order-preserving float32 <-> uint32 (handles negative values; NaN sorts last)

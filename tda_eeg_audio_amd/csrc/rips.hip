@@ -995,11 +995,13 @@ __device__ void rips_sweep(int n, int E, int Ev, const u16* rank, const u16* ord
                 u32 mycode = 0u, myrk = 0u;
                 float mybirth = 0.f;
                 int nk = 0, more = 0;
+                const int nq = (nl + 63) >> 6;                        // register blocks the list reaches (wave-uniform)
+                PROF_MARK(30);
                 while (true) {
                     u32 mk = 0xffffffffu;
 #pragma unroll
                     for (int q = 0; q < LPL; ++q)
-                        if (pnz(ev[q]) && ek[q] < mk) mk = ek[q];
+                        if (q < nq && pnz(ev[q]) && ek[q] < mk) mk = ek[q];
                     const u32 best = wave_min_u32_dpp(mk);
                     if (best == 0xffffffffu) break;
                     if (nk == KMAX) { more = 1; break; }
@@ -1007,7 +1009,7 @@ __device__ void rips_sweep(int n, int E, int Ev, const u16* rank, const u16* ord
                     Psi<W, WT> mine = pzero<W, WT>();
 #pragma unroll
                     for (int q = 0; q < LPL; ++q)
-                        if (ek[q] == best) mine = ev[q];
+                        if (q < nq && ek[q] == best) mine = ev[q];
                     Psi<W, WT> wv;
 #pragma unroll
                     for (int c = 0; c < W; ++c) {
@@ -1072,6 +1074,7 @@ __device__ void rips_sweep(int n, int E, int Ev, const u16* rank, const u16* ord
                     // substitute into the vectors still waiting (the killer itself becomes zero)
 #pragma unroll
                     for (int q = 0; q < LPL; ++q) {
+                        if (q >= nq) break;
                         WT sel = 0;
 #pragma unroll
                         for (int c = 0; c < W; ++c)
@@ -1084,6 +1087,7 @@ __device__ void rips_sweep(int n, int E, int Ev, const u16* rank, const u16* ord
                     ++nk;
                     PROF_COUNT(10, 1);
                 }
+                PROF_MARK(31);
                 if (FTAB) {
                     // diagram rows of this round, one kill per lane; the image table for the rewrite
                     const bool mine_ok = lane < nk;
