@@ -287,7 +287,10 @@ def main():
                 return json.load(open(path))
             except Exception:
                 return None
-        traffic = (prof("traffic.json") or {}).get(DOM)
+        tr = prof("traffic.json") or {}
+        traffic = tr.get(DOM)
+        if traffic is not None and tr.get("_windows_per_launch"):        # counted at another launch size: scale it
+            traffic = int(round(traffic * n_win_batch / tr["_windows_per_launch"]))
         line = {
             "metric": "windows/sec end-to-end (dist->Rips H0/H1->Wasserstein), 47-ch EEG",
             "value": value, "unit": "windows/s", "n_gpus": world, "steps": args.steps, "warmup": max(1, args.warmup),

@@ -50,23 +50,28 @@ for d, ctr in (("prof_fetch", "FETCH_SIZE"), ("prof_write", "WRITE_SIZE")):
 json.dump(pmc, open(os.path.join(out, f"{tag}_pmc_summary.json"), "w"), indent=1)
 
 STAGE_KERNEL = {
-    "corr_dist": "corr_dist_kernel", "rips_eeg": "rips_dm_kernel<256, 1, 1", "rips_audio": "rips_cloud_kernel<512, 1, unsigned int",
+    "eeg_window": "eeg_window_kernel<3, false, 1, false", "corr_dist": "corr_dist_kernel",
+    "rips_eeg": "rips_dm_kernel<256, 1, 1, unsigned long long, false", "rips_audio": "rips_cloud_kernel<512, 1, unsigned int, false",
     "wasserstein_h0": "wasserstein_kernel<2", "wasserstein_h1": "wasserstein_kernel<4", "tau": "tau_kernel",
+    "finish": "diagram_finish_kernel",
 }
-# gfx950: FETCH_SIZE reports half of the bytes of wide coalesced streaming reads (MI355X_MICROARCH.md).  corr_dist reads
-# its windows as 512 contiguous bytes per wave instruction and shows exactly that (34 MB counted vs 66.7 MB read);
+# gfx950: FETCH_SIZE reports half of the bytes of wide coalesced streaming reads (MI355X_MICROARCH.md).  The window
+# fetch of corr_dist / the fused EEG kernel reads 512 contiguous bytes per wave instruction and shows exactly that;
 # the other kernels gather 8 B per lane from short rows and are left as counted.
-FETCH_X2 = {"corr_dist"}
+FETCH_X2 = {"corr_dist", "eeg_window"}
 traffic = {}
+launch_windows = None
 for stage, pat in STAGE_KERNEL.items():
     for k, e in pmc.items():
         if k.startswith(pat) or pat in k:
             fetch = e.get("FETCH_SIZE_KB_avg_per_launch", 0.0) * (2.0 if stage in FETCH_X2 else 1.0)
             traffic[stage] = int(round((fetch + e.get("WRITE_SIZE_KB_avg_per_launch", 0.0)) * 1024))
             break
-traffic["_note"] = ("HBM bytes per launch of the first-pass kernel of each stage (710 windows): rocprofv3 --pmc FETCH_SIZE and "
-                    "--pmc WRITE_SIZE in separate passes (KB -> bytes).  gfx950 correction: FETCH_SIZE doubled for corr_dist "
-                    "(wide coalesced streaming reads are tallied at half their size); the other kernels gather 8 B per lane "
-                    "and are left as counted.")
+traffic["_windows_per_launch"] = 3540
+traffic["_note"] = ("HBM bytes per launch of the first-pass kernel of each stage, at 3,540 windows per launch (the reduced corpus "
+                    "of tools/collect_profiles.sh): rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (KB -> "
+                    "bytes).  gfx950 correction: FETCH_SIZE doubled for the window fetch of corr_dist / eeg_window (wide "
+                    "coalesced streaming reads are tallied at half their size); the other kernels gather 8 B per lane and "
+                    "are left as counted.  bench.py scales the figure to its own windows per launch.")
 json.dump(traffic, open(os.path.join(out, "traffic.json"), "w"), indent=1)
 print(json.dumps(traffic, indent=1))
