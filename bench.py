@@ -312,6 +312,7 @@ def main():
                        "windows_repaired": {"eeg": int(retry_after[0] - retry_before[0]),
                                             "audio": int(retry_after[1] - retry_before[1]),
                                             "note": "windows redone by the widening passes inside the timed steps"},
+                       "batches_rerun_with_full_ladder": lanes.repairs,
                        "result_rows_finite_frac": round(finite_frac, 6),
                        "data_generation_s": round(t_gen, 2)},
             "stage_ms": {s: round(v, 4) for s, v in stage_ms.items()},     # one eager pass, band batches one at a time
@@ -355,6 +356,8 @@ def features_leg(args, ctx, device, mine, shards, n_rec, rank, world, nb):
     ws = pipeline.Workspace(n_win, seg_off, device)
     block = torch.empty((len(mine), nb, 44), dtype=torch.float64, device=device)
 
+    ctx.set_retry_policy(ctx.RETRY_ONE_STEP)      # (a status word left non-zero shows in windows_bad_status below)
+
     def one_pass():
         for b in range(nb):
             block[:, b].copy_(pipeline.run_features_step(eeg[b], ws, ctx=ctx))
@@ -375,6 +378,7 @@ def features_leg(args, ctx, device, mine, shards, n_rec, rank, world, nb):
         t = torch.tensor([dt], dtype=torch.float64, device="cpu" if args.share_gpu else device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+    ctx.set_retry_policy(ctx.RETRY_AUTO)
     bad = int((ws.eeg.status != 0).sum().item())
     total = n_rec * nb * fw
     del eeg, ws

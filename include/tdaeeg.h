@@ -74,10 +74,15 @@ tda_status tda_set_class_words(tda_ctx* ctx, int words_dm, int words_cloud);
  * FIRST_PASS: only the first pass is launched; flagged windows keep the status bit and invalid rows.  A
  *   streaming caller checks the statuses once they have reached the host and, if any is set, calls the same
  *   entry point again on the same buffers under RETRY_ONLY (then recomputes what depends on the diagrams).
- * RETRY_ONLY: only the widening passes (and the row ordering) are launched. */
+ * RETRY_ONLY: only the widening passes (and the row ordering) are launched.
+ * ONE_STEP: the first pass and ONE widening pass (the next rung of the ladder: 128 bits for matrices, 64 for
+ *   clouds), which catches nearly every flagged window and still fits beside the other kernels of a busy GPU; the
+ *   wide rungs (up to 95 KB of LDS and 256 VGPRs per workgroup, which wait for a nearly empty CU even when they have
+ *   nothing to redo) are left to a later RETRY_ONLY call for the batches whose statuses still carry the bit. */
 #define TDA_RETRY_AUTO       0
 #define TDA_RETRY_FIRST_PASS 1
 #define TDA_RETRY_ONLY       2
+#define TDA_RETRY_ONE_STEP   3
 tda_status tda_set_retry_policy(tda_ctx* ctx, int policy);
 /* Optional accounting of the widening passes: dev_counters = DEVICE u64[2] (or NULL to stop).  Every window a
  * widening pass redoes adds one to [0] (distance-matrix input, tda_rips_dm_batch) or [1] (point clouds,

@@ -147,7 +147,7 @@ class Context:
     def set_class_words(self, words_dm=2, words_cloud=1):
         self.check(self.lib.tda_set_class_words(self.h, words_dm, words_cloud))
 
-    RETRY_AUTO, RETRY_FIRST_PASS, RETRY_ONLY = 0, 1, 2
+    RETRY_AUTO, RETRY_FIRST_PASS, RETRY_ONLY, RETRY_ONE_STEP = 0, 1, 2, 3
 
     def set_retry_policy(self, policy):
         self.check(self.lib.tda_set_retry_policy(self.h, int(policy)))

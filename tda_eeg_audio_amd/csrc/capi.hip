@@ -85,7 +85,7 @@ tda_status tda_set_retry_counter(tda_ctx* ctx, void* dev_counters)
 tda_status tda_set_retry_policy(tda_ctx* ctx, int policy)
 {
     if (!ctx) return TDA_ERR_INVALID;
-    if (policy < TDA_RETRY_AUTO || policy > TDA_RETRY_ONLY) TDA_FAIL(ctx, TDA_ERR_INVALID, "unknown retry policy");
+    if (policy < TDA_RETRY_AUTO || policy > TDA_RETRY_ONE_STEP) TDA_FAIL(ctx, TDA_ERR_INVALID, "unknown retry policy");
     ctx->retry_policy = policy;
     return TDA_OK;
 }

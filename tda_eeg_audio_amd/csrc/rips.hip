@@ -60,10 +60,10 @@
 #ifdef TDA_PROFILE
 // Per-workgroup sums live in LDS (thread 0 adds, no atomics) and are flushed to the global table once per
 // window: hundreds of workgroups hammering the same global counters at every mark cost more than the phases.
-__device__ unsigned long long g_prof[32];
-__shared__ unsigned long long prof_lds[32];
+__device__ unsigned long long g_prof[48];
+__shared__ unsigned long long prof_lds[48];
 #define PROF_BEGIN()                                                       \
-    if (threadIdx.x < 32) prof_lds[threadIdx.x] = 0ull;                    \
+    if (threadIdx.x < 48) prof_lds[threadIdx.x] = 0ull;                    \
     __syncthreads();                                                       \
     unsigned long long prof_t0 = clock64()
 #define PROF_RESUME() unsigned long long prof_t0 = clock64()
@@ -77,13 +77,20 @@ __shared__ unsigned long long prof_lds[32];
 #define PROF_FLUSH()                                                       \
     do {                                                                   \
         __syncthreads();                                                   \
-        if (threadIdx.x < 32 && prof_lds[threadIdx.x]) atomicAdd(&g_prof[threadIdx.x], prof_lds[threadIdx.x]); \
+        if (threadIdx.x < 48 && prof_lds[threadIdx.x]) atomicAdd(&g_prof[threadIdx.x], prof_lds[threadIdx.x]); \
     } while (0)
+// experiment knob of the diagnostic build: the Rips kernels return after phase n (1: keys, 2: ranking); 0 = run all
+__device__ int g_stop_after;
+extern "C" __attribute__((visibility("default"))) int tda_profile_stop_after(int n)
+{
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_stop_after), &n, sizeof(int)) != hipSuccess;
+}
+#define PROF_STOP(n, cleanup) do { if (g_stop_after == (n)) { cleanup; return; } } while (0)
 extern "C" __attribute__((visibility("default"))) int tda_profile_read(unsigned long long* out, int reset)
 {
-    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_prof), sizeof(unsigned long long) * 32) != hipSuccess) return 1;
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_prof), sizeof(unsigned long long) * 48) != hipSuccess) return 1;
     if (reset) {
-        unsigned long long z[32] = {0};
+        unsigned long long z[48] = {0};
         if (hipMemcpyToSymbol(HIP_SYMBOL(g_prof), z, sizeof(z)) != hipSuccess) return 1;
     }
     return 0;
@@ -94,6 +101,7 @@ extern "C" __attribute__((visibility("default"))) int tda_profile_read(unsigned 
 #define PROF_MARK(i) do {} while (0)
 #define PROF_COUNT(i, v) do {} while (0)
 #define PROF_FLUSH() do {} while (0)
+#define PROF_STOP(n, cleanup) do {} while (0)
 #endif
 
 #define WAVE_SYNC()                                            \
@@ -787,8 +795,13 @@ __device__ void rips_sweep(int n, int E, int Ev, const u16* rank, const u16* ord
             pending = false;
         }
         if (!pending) done[tid] = 1;        // candidates, idle lanes and the lanes above are settled
+#ifdef TDA_PROFILE
+        if (pending) atomicAdd(&prof_lds[33], 1ull);
+        PROF_COUNT(34, 1);
+#endif
         // rounds for the rest: a lane is ready when both dependencies are settled
         while (wg_any<NT>(vote, pending)) {
+            PROF_COUNT(32, 1);
             bool ready = false;
             if (pending) ready = (q1 < 0 || done[q1]) && (q2 < 0 || done[q2]);
             __syncthreads();                 // all flag reads of this round precede its flag writes
@@ -1510,8 +1523,10 @@ __device__ void rips_cloud_window(unsigned char* smem, const int win, const doub
     u32 teff, kmin;
     const int Ev = count_effective_edges<NT>(key32, E, P, tkey, vmax, red, teff, kmin);
     PROF_MARK(0);
+    PROF_STOP(1, if (tid == 0) { out.h0_cnt[win] = 0; out.h1_cnt[win] = 0; out.status[win] = 0; });
     rank_edges<NT, 8192, false>(key32, E, teff, kmin, members, cursor, wsum, rank, ord, nullptr);
     PROF_MARK(1);
+    PROF_STOP(2, if (tid == 0) { out.h0_cnt[win] = 0; out.h1_cnt[win] = 0; out.status[win] = 0; });
     guard_write(smem, L);
     int k0, k1, st;
     if (P <= 64)
@@ -1733,6 +1748,7 @@ tda_status launch_rips_dm(tda_ctx* ctx, const double* dm, int n_win, int n, doub
     // largest class capacity that still fits the 160 KiB LDS
     while (W > 1 && make_layout(n, W * 8, n * (n - 1) / 2 * 4, 256).total > LDS_MAX) W >>= 1;
     const bool do_first = ctx->retry_policy != TDA_RETRY_ONLY, do_ladder = ctx->retry_policy != TDA_RETRY_FIRST_PASS;
+    const bool one_step = ctx->retry_policy == TDA_RETRY_ONE_STEP;
     rc = TDA_OK;
     if (n <= 64) {
         if (!do_first) {}
@@ -1743,6 +1759,7 @@ tda_status launch_rips_dm(tda_ctx* ctx, const double* dm, int n_win, int n, doub
         // the table still fits LDS (n <= 47: 512 bits cover the theoretical maximum of 506 alive
         // classes).  A retry launch whose windows are all fine exits at once.
         for (int Wr = 2 * W; do_ladder && rc == TDA_OK && Wr <= 8; Wr *= 2) {
+            if (one_step && Wr > 2 * W) break;
             if (make_layout(n, Wr * 8, n * (n - 1) / 2 * 4, 256).total > LDS_MAX) break;
             if (Wr == 2) rc = launch_dm_t<1, 2>(ctx, dm, n_win, n, th, symmetrise, out, st, 1);
             else if (Wr == 4) rc = launch_dm_t<1, 4>(ctx, dm, n_win, n, th, symmetrise, out, st, 1);
@@ -1795,7 +1812,7 @@ static tda_status launch_eeg_ladder(tda_ctx* ctx, const double* win, int n_win, 
     // 512, which covers the theoretical maximum of 506 classes alive at once for 47 points
     if (do_ladder && rc == TDA_OK && W == 1)
         rc = launch_eeg_t<3, RES, 2, true>(ctx, win, n_win, n_ch, n_t, th, out, dist, corr, st);
-    if (do_ladder && rc == TDA_OK)
+    if (do_ladder && rc == TDA_OK && !(ctx->retry_policy == TDA_RETRY_ONE_STEP && W == 1))
         rc = launch_eeg_t<3, RES, 8, true>(ctx, win, n_win, n_ch, n_t, th, out, dist, corr, st);
     return rc;
 }
@@ -1882,7 +1899,7 @@ tda_status launch_rips_cloud(tda_ctx* ctx, const double* src, const int* aux, in
     if (rc == TDA_OK && (first ? do_first : do_ladder))
         rc = launch_cloud_t<1, u64>(ctx, src, aux, n_win, n_t_or_pcap, dim, subsample, mode, normalise, th, p_max,
                                     n_points, out, st, first ? 0 : 1);
-    if (do_ladder && rc == TDA_OK && fits128)
+    if (do_ladder && rc == TDA_OK && fits128 && !(ctx->retry_policy == TDA_RETRY_ONE_STEP && !first))
         rc = launch_cloud_t<2, u64>(ctx, src, aux, n_win, n_t_or_pcap, dim, subsample, mode, normalise, th, p_max,
                                     n_points, out, st, 1);
     if (rc != TDA_OK) return rc;

@@ -59,19 +59,21 @@ def run_step(eeg_win, audio_win, ws, ctx=None, max_lag=125, timers=None, retry="
     f64, both resident in HBM.  Returns ws.result (n_seg, 48).  `timers`: optional dict of
     (start,end) torch.cuda.Event pairs per stage, recorded on the launch stream.
     retry="auto": every Rips call launches its widening passes (exact by itself).  retry="first": first passes
-    only; the class-overflow bits of the batch are copied to ws.flags_host (pinned) at the end of the step and
-    the caller re-runs the step with retry="auto" if any is set (pipeline.Lanes does)."""
+    only; retry="one": first passes plus ONE widening pass each (TDA_RETRY_ONE_STEP: the wide rungs of the ladder
+    wait for a nearly empty CU even when they have nothing to redo).  In both cases the class-overflow bits that are
+    left are copied to ws.flags_host (pinned) at the end of the step and the caller re-runs the step with
+    retry="auto" if any is set (pipeline.Lanes does: verify, then publish)."""
     import torch
     from . import _lib
     ctx = ctx or _lib.get_ctx()
-    if retry == "first":
-        ctx.set_retry_policy(ctx.RETRY_FIRST_PASS)
+    if retry != "auto":
+        ctx.set_retry_policy(ctx.RETRY_FIRST_PASS if retry == "first" else ctx.RETRY_ONE_STEP)
     ctx.set_h1_order(ctx.ORDER_DEFERRED)         # one finishing pass for the three diagram sets of the batch
     try:
         return _run_step(eeg_win, audio_win, ws, ctx, max_lag, timers, retry)
     finally:
         ctx.set_h1_order(ctx.ORDER_IN_CALL)
-        if retry == "first":
+        if retry != "auto":
             ctx.set_retry_policy(ctx.RETRY_AUTO)
 
 
@@ -120,7 +122,7 @@ def _run_step(eeg_win, audio_win, ws, ctx, max_lag, timers, retry):
     # features (v2:429-436) -- one launch
     stage("reduce", lambda: engine.recording_rows_dev(ws.w0, ws.w1, ws.tau_seg, ws.fe0, ws.fe1, ws.seg_off, ws.result,
                                                       ws.eeg.status, ws.aud.status, ws.seg_flags, ctx=ctx))
-    if retry == "first":
+    if retry != "auto":
         ws.flags_host.copy_(ws.seg_flags, non_blocking=True)
     return ws.result
 
@@ -165,7 +167,7 @@ class Lanes:
         self.streams = [torch.cuda.Stream(device=device) for _ in range(self.depth)]
         self.k = 0
         self.graph = bool(graph)
-        self.defer = bool(defer_retries)
+        self.defer = defer_retries if defer_retries == "one" else bool(defer_retries)
         self.graphs = {}
         self.pending = [None] * self.depth
         self.repairs = 0
@@ -200,7 +202,7 @@ class Lanes:
         st, ws = self.streams[i], self.ws[i]
         if sync_inputs:                                      # inputs produced on the caller's stream; pass False when
             st.wait_stream(torch.cuda.current_stream())     # they are resident and unchanged (costs ~0.07 ms per step)
-        retry = "first" if self.defer else "auto"
+        retry = ("one" if self.defer == "one" else "first") if self.defer else "auto"
         key = (i, eeg_win.data_ptr(), audio_win.data_ptr(), int(max_lag), id(ctx))
         if self.graph and timers is None:
             g = self.graphs.get(key)
@@ -262,9 +264,10 @@ class CorpusPass:
             assert n_win % wpr == 0
             seg_off = np.arange(0, n_win + 1, wpr, dtype=np.int32)
         self.n_rec, self.n_win = len(seg_off) - 1, n_win
-        # big batches: the widening passes ride along with every step (a small strided grid each; their cost is
-        # noise next to a batch of thousands of windows, and no host round trip is needed)
-        lane_kw.setdefault("defer_retries", False)
+        # big batches: ONE widening pass rides along with every Rips call (a few windows in ten thousand need it, and
+        # it fits beside the other kernels); the wide rungs of the ladder, which would wait for a nearly empty CU
+        # even with nothing to redo, run only for a batch whose flags are still set when it is verified
+        lane_kw.setdefault("defer_retries", "one")
         self.lanes = Lanes(depth, n_win, seg_off, device, graph=graph, **lane_kw)
         self.blocks = [torch.empty((self.n_rec, self.n_bands, RESULT_COLS), dtype=torch.float64, device=device)
                        for _ in range(3)]
