@@ -449,27 +449,39 @@ def cpu_baseline(eeg, aud, wpr, budget_s, n_rec=8):
     return json.loads(out.stdout.strip().splitlines()[-1])
 
 
-def _cpu_group(job):
+_CPU_GROUPS = None
+
+
+def _cpu_group(i):
     from oracle import port
-    e, a = job
+    e, a = _CPU_GROUPS[i % len(_CPU_GROUPS)]
     t0 = time.perf_counter()
     port.segment_step(e, a)
     return time.perf_counter() - t0
 
 
-def _cpu_init():
+def _cpu_load(path):
+    """(eeg, aud) of every (recording, band) group of the sample, recording-major."""
+    global _CPU_GROUPS
+    z = np.load(path)
+    eeg, aud, wpr = z["eeg"], z["aud"], int(z["wpr"])
+    nb, n = eeg.shape[0], eeg.shape[1]
+    _CPU_GROUPS = [(np.ascontiguousarray(eeg[b, r:r + wpr]), np.ascontiguousarray(aud[b, r:r + wpr]))
+                   for r in range(0, n, wpr) for b in range(nb)]
+    return wpr, nb, n, float(z["budget"])
+
+
+def _cpu_init(path):
     from oracle import port
     port.use_native()
+    _cpu_load(path)                         # every worker holds the sample: a job is an index, nothing is pickled
 
 
 def cpu_worker(path):
     import multiprocessing as mp
     from oracle import port                 # the ONLY use of oracle/ in this file: the timed CPU port
     flags = port.use_native()
-    z = np.load(path)
-    eeg, aud, wpr, budget = z["eeg"], z["aud"], int(z["wpr"]), float(z["budget"])
-    nb, n = eeg.shape[0], eeg.shape[1]
-    groups = [(eeg[b, r:r + wpr], aud[b, r:r + wpr]) for r in range(0, n, wpr) for b in range(nb)]   # recording-major
+    wpr, nb, n, budget = _cpu_load(path)
     cpu_model = "unknown"
     phys = set()
     try:
@@ -487,18 +499,18 @@ def cpu_worker(path):
     avail = len(os.sched_getaffinity(0))
     workers = max(1, min(avail, int(os.environ.get("TDA_CPU_WORKERS", "16"))))
     # ---- one core: >= 5 samples, each one recording (nb groups) ----
-    _cpu_group(groups[0])                                            # warm
+    _cpu_group(0)                                                    # warm
     samples1, t_spent, i = [], 0.0, 0
     while len(samples1) < 5 or (t_spent < 0.4 * budget and len(samples1) < 50):
-        t = sum(_cpu_group(groups[(i * nb + j) % len(groups)]) for j in range(nb))
+        t = sum(_cpu_group(i * nb + j) for j in range(nb))
         samples1.append(nb * wpr / t)
         t_spent += t
         i += 1
     # ---- all cores: a pool over the groups, >= 5 samples of `workers` x 2 groups each ----
     samples_n = []
-    with mp.get_context("fork").Pool(workers, initializer=_cpu_init) as pool:
-        batch = [groups[j % len(groups)] for j in range(2 * workers)]
-        pool.map(_cpu_group, batch)                                      # warm
+    with mp.get_context("fork").Pool(workers, initializer=_cpu_init, initargs=(path,)) as pool:
+        batch = list(range(4 * workers))
+        pool.map(_cpu_group, batch, chunksize=1)                         # warm
         t_spent = 0.0
         while len(samples_n) < 5 or (t_spent < 0.5 * budget and len(samples_n) < 50):
             t0 = time.perf_counter()
@@ -514,7 +526,7 @@ def cpu_worker(path):
         "sample": f"oracle/tda_oracle.c::orc_segment_step ({flags}), the same end-to-end unit on whole (recording, band) "
                   f"groups of {wpr} window pairs drawn from {n // wpr} recordings x {nb} bands of this workload; 1 core: "
                   f"median of {len(samples1)} samples of {nb} groups; all cores: process pool of {workers} over the "
-                  f"groups (v2:569-572 joblib processes), median of {len(samples_n)} samples of {2 * workers} groups; "
+                  f"groups (v2:569-572 joblib processes), median of {len(samples_n)} samples of {4 * workers} groups; "
                   f"RESTATED baseline (ripser/persim are not installable offline)",
         "samples_1core": [round(x, 1) for x in samples1[:10]], "samples_all_cores": [round(x, 1) for x in samples_n[:10]]}))
     return 0
