@@ -271,6 +271,7 @@ def main():
             extras["features_pass"] = features_leg(args, ctx, device, mine, shards, n_rec, rank, world, nb)
         if rank == 0:
             extras["pcie_inclusive"] = pcie_leg(ctx, device, eeg[nb - 2], aud[nb - 2], wpr)
+            extras["front_end_inclusive"] = front_end_leg(ctx, device, args.features_windows)
 
     if rank == 0:
         value = total_pairs * args.steps / dt
@@ -422,6 +423,48 @@ def pcie_leg(ctx, device, eeg_b, aud_b, wpr, n_rec=256):
     return {"value": n_win / dt, "unit": "windows/s", "stage": "h2d + step + d2h, one stream, pinned host buffers",
             "sample": f"{n_win} window pairs of one band ({nbytes / 1e6:.0f} MB uploaded per step)",
             "h2d_GBps": nbytes / dt / 1e9, "ms_per_step": dt * 1e3}
+
+
+def front_end_leg(ctx, device, n_sel, n_rec=354, n_samples=4606):
+    """Front-end-inclusive rate of the EEG half (never `value`): RAW recordings (47 x 4,606 samples = 71 windows, the
+    first row of results/preprocessing_metadata.csv) in pinned host memory -> HBM -> five zero-phase band-passes of all
+    channels -> fused window kernel on the sliding windows read in place (n_sel evenly spaced windows per
+    recording-band) -> features -> (n_rec, 220) matrix back on the host.  1.73 MB uploaded per recording instead of the
+    33 MB of its five (71, 47, 250) window stacks (43 GB for the corpus)."""
+    import torch
+    from tda_eeg_audio_amd import preprocess
+    g = torch.Generator(device=device)
+    g.manual_seed(777)
+    raw_d = torch.randn((n_rec, 47, n_samples), generator=g, dtype=torch.float64, device=device)
+    raw_d += 0.5 * torch.randn((n_rec, 1, n_samples), generator=g, dtype=torch.float64, device=device)
+    raw_h = raw_d.cpu().pin_memory()
+    per_rec = (n_samples - 250) // 62 + 1
+    pick = np.linspace(0, per_rec - 1, n_sel, dtype=int)
+    sel = (np.arange(n_rec)[:, None] * per_rec + pick[None, :]).astype(np.int32).ravel()
+    sel_t = torch.from_numpy(sel).to(device)
+    out_h = torch.empty((n_rec, 220), dtype=torch.float64).pin_memory()
+
+    def step():
+        raw_d.copy_(raw_h, non_blocking=True)
+        X, st = preprocess.recordings_to_features(raw_d, 250, sel_t=sel_t, n_sel_per_rec=n_sel, ctx=ctx)
+        out_h.copy_(X, non_blocking=True)
+        return st
+    st = step()
+    torch.cuda.synchronize()
+    bad = int((st != 0).sum().item())
+    t0 = time.perf_counter()
+    K = 4
+    for _ in range(K):
+        step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / K
+    n_win = n_rec * 5 * n_sel
+    return {"value": n_win / dt, "unit": "windows/s", "ms_per_step": dt * 1e3,
+            "stage": "raw EEG h2d + 5 x sosfiltfilt (all channels, one launch each) + fused sliding-window kernel + features "
+                     "+ aggregation + d2h, one stream",
+            "sample": f"{n_rec} recordings x 47 channels x {n_samples} samples ({raw_h.numel() * 8 / 1e6:.0f} MB uploaded per step), "
+                      f"{n_sel} of {per_rec} windows per recording-band = {n_win} windows",
+            "matrix_finite": bool(torch.isfinite(out_h).all().item()), "windows_bad_status": bad}
 
 
 # ------------------------------------------------------------------------------------------------------------

@@ -150,6 +150,19 @@ tda_status tda_eeg_window_batch_dev(tda_ctx* ctx, const double* win, int n_win, 
                                     double* dist, double* corr, double* h0, int h0_cap, int* h0_cnt,
                                     double* h1, int h1_cap, int* h1_cnt, int* status, void* stream);
 
+/* The same kernel on windows read IN PLACE from band-passed recordings of equal length, sig: (n_rec, n_ch,
+ * n_samples) float64 -- create_sliding_windows (notebooks/1_preprocesamiento.ipynb:314-381: window k of a recording =
+ * samples [k*step, k*step + win_len), n_win_per_rec = (n_samples - win_len) / step + 1) + process_file_graphs
+ * (nb2:198-207) + compute_eeg_persistence (utils.py:135-141) without ever materialising the (n_win, n_ch, win_len)
+ * stack (4x the bytes at 75 % overlap; 43 GB for the corpus) or the matrices.  sel (nullable, n_sel entries): the
+ * windows to process, as r * n_win_per_rec + k -- the drivers' window selection (v2:394-398, cmp:77-80); outputs
+ * have n_sel rows then, otherwise n_rec * n_win_per_rec (recording-major).  n_win_per_rec (out, nullable, host). */
+tda_status tda_eeg_window_sliding_dev(tda_ctx* ctx, const double* sig, int n_rec, int n_ch, int n_samples,
+                                      int win_len, int step, const int* sel, int n_sel, double thresh,
+                                      double* dist, double* corr, double* h0, int h0_cap, int* h0_cnt,
+                                      double* h1, int h1_cap, int* h1_cnt, int* status, int* n_win_per_rec,
+                                      void* stream);
+
 /* ---- Takens embedding + Rips (audio branch) ---------------------------------
  * replaces takens_embedding (scripts/utils.py:107-116) followed by
  * compute_audio_persistence (utils.py:123-132): per-column min-max to [0,1],

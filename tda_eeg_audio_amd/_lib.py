@@ -41,6 +41,8 @@ SYMBOLS = {
     "tda_corr_to_dist_batch": (_I, [c_vp, c_vp, _I, _I, _I, c_vp]),
     "tda_rips_dm_batch_dev": (_I, [c_vp, c_vp, _I, _I, _D, _I, c_vp, _I, c_vp, c_vp, _I, c_vp, c_vp, c_vp]),
     "tda_eeg_window_batch_dev": (_I, [c_vp, c_vp, _I, _I, _I, _D, c_vp, c_vp, c_vp, _I, c_vp, c_vp, _I, c_vp, c_vp, c_vp]),
+    "tda_eeg_window_sliding_dev": (_I, [c_vp, c_vp, _I, _I, _I, _I, _I, c_vp, _I, _D, c_vp, c_vp, c_vp, _I, c_vp, c_vp, _I,
+                                        c_vp, c_vp, c_vp, c_vp]),
     "tda_rips_dm_batch": (_I, [c_vp, c_vp, _I, _I, _D, _I, c_vp, _I, c_vp, c_vp, _I, c_vp, c_vp]),
     "tda_takens_rips_batch_dev": (_I, [c_vp, c_vp, c_vp, _I, _I, _I, _I, _D, c_vp, _I, c_vp, c_vp, _I, c_vp,
                                        c_vp, c_vp, c_vp]),

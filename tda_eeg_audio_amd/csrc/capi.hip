@@ -145,6 +145,20 @@ tda_status tda_eeg_window_batch_dev(tda_ctx* ctx, const double* win, int n_win, 
                               status, (hipStream_t)stream);
 }
 
+tda_status tda_eeg_window_sliding_dev(tda_ctx* ctx, const double* sig, int n_rec, int n_ch, int n_samples, int win_len,
+                                      int step, const int* sel, int n_sel, double thresh, double* dist, double* corr,
+                                      double* h0, int h0_cap, int* h0_cnt, double* h1, int h1_cap, int* h1_cnt,
+                                      int* status, int* n_win_per_rec, void* stream)
+{
+    CHECK_CTX(ctx); CHECK_NONNEG(ctx, n_rec); CHECK_NONNEG(ctx, n_sel);
+    if (n_rec) { CHECK_PTR(ctx, sig); CHECK_PTR(ctx, h0); CHECK_PTR(ctx, h0_cnt); CHECK_PTR(ctx, h1);
+                 CHECK_PTR(ctx, h1_cnt); CHECK_PTR(ctx, status); }
+    if (corr && !dist) TDA_FAIL(ctx, TDA_ERR_INVALID, "corr needs dist");
+    if (h1_cap < 1) TDA_FAIL(ctx, TDA_ERR_INVALID, "h1_cap must be >= 1");
+    return launch_eeg_sliding(ctx, sig, n_rec, n_ch, n_samples, win_len, step, sel, n_sel, thresh, dist, corr, h0, h0_cap,
+                              h0_cnt, h1, h1_cap, h1_cnt, status, n_win_per_rec, (hipStream_t)stream);
+}
+
 tda_status tda_takens_rips_batch_dev(tda_ctx* ctx, const double* win, const int* tau, int n_win, int n_t, int dim,
                                      int subsample, double thresh, double* h0, int h0_cap, int* h0_cnt, double* h1,
                                      int h1_cap, int* h1_cnt, int* n_points, int* status, void* stream)

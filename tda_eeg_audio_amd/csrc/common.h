@@ -148,6 +148,8 @@ tda_status launch_rips_dm(tda_ctx*, const double*, int, int, double, int, double
                           int*, hipStream_t);
 tda_status launch_eeg_windows(tda_ctx*, const double*, int, int, int, double, double*, double*, double*, int, int*, double*,
                               int, int*, int*, hipStream_t);
+tda_status launch_eeg_sliding(tda_ctx*, const double*, int, int, int, int, int, const int*, int, double, double*, double*,
+                              double*, int, int*, double*, int, int*, int*, int*, hipStream_t);
 tda_status launch_rips_cloud(tda_ctx*, const double* win_or_pc, const int* tau_or_npts, int n_win, int n_t_or_pcap,
                              int dim, int subsample, int mode, int normalise, double thresh, double*, int, int*,
                              double*, int, int*, int* n_points, int*, hipStream_t);

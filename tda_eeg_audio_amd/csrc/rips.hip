@@ -1595,14 +1595,29 @@ rips_cloud_kernel(const double* __restrict__ src, const int* __restrict__ tau_or
 // for operation, so the diagrams are bit-identical to the two-kernel path.  dist / corr (optional) receive the
 // matrices as corr_dist_kernel writes them.
 // ---------------------------------------------------------------------------------
+// where the windows of a launch live: stacked (preprocessed/<rec>/<band>.npy: win_stride = n_ch * n_t, ld = n_t, one
+// group) or sliding over band-passed recordings of equal length (n_rec, n_ch, n_samples): window k of recording r
+// starts at r * group_stride + k * win_stride, row stride ld = n_samples -- create_sliding_windows
+// (notebooks/1_preprocesamiento.ipynb:314-381) without the 4x overlapping stack.  sel (optional): the windows to
+// process, as indices r * wins_per_group + k (the window selection of the drivers).
+struct WindowSource {
+    const double* base; long long win_stride, group_stride; int ld, wins_per_group; const int* sel;
+    __device__ __forceinline__ const double* at(int w) const
+    {
+        const int g = sel ? sel[w] : w;
+        const int r = g / wins_per_group, k = g - r * wins_per_group;
+        return base + (size_t)r * (size_t)group_stride + (size_t)k * (size_t)win_stride;
+    }
+};
+
 template <int NB, bool RES, int W>
-__device__ __forceinline__ void eeg_one_window(unsigned char* smem, const double* __restrict__ windows, int w, int n_ch,
+__device__ __forceinline__ void eeg_one_window(unsigned char* smem, const WindowSource& src, int w, int n_ch,
                                                int n_t, float thresh, const RipsLayout& L, const RipsOut& out,
                                                double* __restrict__ dist, double* __restrict__ corr)
 {
     const int tid = threadIdx.x, l = tid & 63, wv = tid >> 6;
     PROF_BEGIN();
-    cd_window_products<NB, RES>(smem, windows + (size_t)w * n_ch * n_t, n_ch, n_t, n_t);
+    cd_window_products<NB, RES>(smem, src.at(w), n_ch, n_t, src.ld);
     const double* accs = reinterpret_cast<const double*>(smem) + CdLayout<NB>::TILE;
     const double* sdev = accs + CdLayout<NB>::ACCS + CdLayout<NB>::CP;
     const double fact = 1.0 / (double)(n_t - 1);
@@ -1654,7 +1669,7 @@ __device__ __forceinline__ void eeg_one_window(unsigned char* smem, const double
 // tests/test_gpu_parity.py::test_fused_eeg_window_512_classes covers the widest one.
 template <int NB, bool RES, int W, bool RETRY>
 __global__ void __launch_bounds__(256, (W > 2 || RETRY) ? 2 : (RES ? 3 : 4))
-eeg_window_kernel(const double* __restrict__ windows, int n_win, int n_ch, int n_t, float thresh, RipsLayout L, RipsOut out,
+eeg_window_kernel(WindowSource windows, int n_win, int n_ch, int n_t, float thresh, RipsLayout L, RipsOut out,
                   double* __restrict__ dist, double* __restrict__ corr, unsigned long long* __restrict__ retry_ctr)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1777,7 +1792,7 @@ tda_status launch_rips_dm(tda_ctx* ctx, const double* dm, int n_win, int n, doub
 }
 
 template <int NB, bool RES, int W, bool RETRY>
-static tda_status launch_eeg_t(tda_ctx* ctx, const double* win, int n_win, int n_ch, int n_t, float thresh, RipsOut out,
+static tda_status launch_eeg_t(tda_ctx* ctx, const WindowSource& win, int n_win, int n_ch, int n_t, float thresh, RipsOut out,
                                double* dist, double* corr, hipStream_t st)
 {
     RipsLayout L = make_layout(n_ch, W * 8, n_ch * (n_ch - 1) / 2 * 4, 256);
@@ -1799,7 +1814,7 @@ static tda_status launch_eeg_t(tda_ctx* ctx, const double* win, int n_win, int n
 }
 
 template <bool RES>
-static tda_status launch_eeg_ladder(tda_ctx* ctx, const double* win, int n_win, int n_ch, int n_t, float th, RipsOut out,
+static tda_status launch_eeg_ladder(tda_ctx* ctx, const WindowSource& win, int n_win, int n_ch, int n_t, float th, RipsOut out,
                                     double* dist, double* corr, hipStream_t st)
 {
     const bool do_first = ctx->retry_policy != TDA_RETRY_ONLY, do_ladder = ctx->retry_policy != TDA_RETRY_FIRST_PASS;
@@ -1817,9 +1832,9 @@ static tda_status launch_eeg_ladder(tda_ctx* ctx, const double* win, int n_win, 
     return rc;
 }
 
-tda_status launch_eeg_windows(tda_ctx* ctx, const double* win, int n_win, int n_ch, int n_t, double thresh, double* dist,
-                              double* corr, double* h0, int h0_cap, int* h0_cnt, double* h1, int h1_cap, int* h1_cnt,
-                              int* status, hipStream_t st)
+static tda_status launch_eeg_source(tda_ctx* ctx, const WindowSource& src, int n_win, int n_ch, int n_t, double thresh,
+                                    double* dist, double* corr, double* h0, int h0_cap, int* h0_cnt, double* h1, int h1_cap,
+                                    int* h1_cnt, int* status, hipStream_t st)
 {
     if (n_win == 0) return TDA_OK;
     if (n_ch < 33 || n_ch > 48) TDA_FAIL(ctx, TDA_ERR_UNSUPPORTED, "the fused EEG kernel takes 33..48 channels (the reference has 47); use tda_corr_dist_batch + tda_rips_dm_batch otherwise");
@@ -1830,10 +1845,33 @@ tda_status launch_eeg_windows(tda_ctx* ctx, const double* win, int n_win, int n_
     // measured 2 % ahead of the form that keeps it in registers between the passes (148 VGPRs, three per CU), which
     // stays available for measurements: TDA_EEG_RESIDENT=1
     static const bool stream_twice = getenv("TDA_EEG_RESIDENT") == nullptr;
-    const tda_status rc = stream_twice ? launch_eeg_ladder<false>(ctx, win, n_win, n_ch, n_t, (float)thresh, out, dist, corr, st)
-                                       : launch_eeg_ladder<true>(ctx, win, n_win, n_ch, n_t, (float)thresh, out, dist, corr, st);
+    const tda_status rc = stream_twice ? launch_eeg_ladder<false>(ctx, src, n_win, n_ch, n_t, (float)thresh, out, dist, corr, st)
+                                       : launch_eeg_ladder<true>(ctx, src, n_win, n_ch, n_t, (float)thresh, out, dist, corr, st);
     if (rc != TDA_OK) return rc;
     return order_h1(ctx, h1, h1_cap, h1_cnt, n_win, st);
+}
+
+tda_status launch_eeg_windows(tda_ctx* ctx, const double* win, int n_win, int n_ch, int n_t, double thresh, double* dist,
+                              double* corr, double* h0, int h0_cap, int* h0_cnt, double* h1, int h1_cap, int* h1_cnt,
+                              int* status, hipStream_t st)
+{
+    const WindowSource src{win, (long long)n_ch * n_t, 0, n_t, 0x7fffffff, nullptr};
+    return launch_eeg_source(ctx, src, n_win, n_ch, n_t, thresh, dist, corr, h0, h0_cap, h0_cnt, h1, h1_cap, h1_cnt, status, st);
+}
+
+// windows read in place from band-passed recordings of equal length (n_rec, n_ch, n_samples); sel: optional window list
+tda_status launch_eeg_sliding(tda_ctx* ctx, const double* sig, int n_rec, int n_ch, int n_samples, int win_len, int step,
+                              const int* sel, int n_sel, double thresh, double* dist, double* corr, double* h0, int h0_cap,
+                              int* h0_cnt, double* h1, int h1_cap, int* h1_cnt, int* status, int* n_win_out, hipStream_t st)
+{
+    if (win_len < 2 || step < 1) TDA_FAIL(ctx, TDA_ERR_INVALID, "win_len must be >= 2 and step >= 1");
+    const int per_rec = n_samples >= win_len ? (n_samples - win_len) / step + 1 : 0;      // nb1:341
+    if (n_win_out) *n_win_out = per_rec;
+    if (n_rec <= 0 || per_rec == 0) return TDA_OK;
+    if ((long long)n_rec * per_rec > 0x7fffffffLL) TDA_FAIL(ctx, TDA_ERR_UNSUPPORTED, "too many windows in one call");
+    const int n_out = sel ? n_sel : n_rec * per_rec;
+    const WindowSource src{sig, (long long)step, (long long)n_ch * n_samples, n_samples, per_rec, sel};
+    return launch_eeg_source(ctx, src, n_out, n_ch, win_len, thresh, dist, corr, h0, h0_cap, h0_cnt, h1, h1_cap, h1_cnt, status, st);
 }
 
 template <int W, typename WT>

@@ -291,6 +291,26 @@ def eeg_window_dev(win_t, out=None, thresh=MAX_EDGE_LENGTH, h1_cap=DEFAULT_H1_CA
     return out
 
 
+def eeg_window_sliding_dev(sig_t, win_len=250, step=62, sel_t=None, out=None, thresh=MAX_EDGE_LENGTH,
+                           h1_cap=DEFAULT_H1_CAP, dist_t=None, corr_t=None, ctx=None):
+    """Fused corr -> dist -> Rips on windows read in place from band-passed recordings sig_t (n_rec, n_ch,
+    n_samples) (nb1:314-381 + nb2:198-207 + utils.py:135-141).  sel_t: optional int32 tensor of window indices
+    r * n_win_per_rec + k.  Returns (diagrams, n_win_per_rec)."""
+    import torch
+    ctx = ctx or get_ctx()
+    assert sig_t.is_cuda and sig_t.dtype == torch.float64 and sig_t.is_contiguous() and sig_t.dim() == 3
+    n_rec, n_ch, n_s = sig_t.shape
+    per_rec = (n_s - win_len) // step + 1 if n_s >= win_len else 0
+    n_out = int(sel_t.numel()) if sel_t is not None else n_rec * per_rec
+    out = out or DeviceDiagrams(n_out, n_ch, h1_cap, sig_t.device)
+    assert out.n_win == n_out
+    ctx.check(ctx.lib.tda_eeg_window_sliding_dev(ctx.h, _tp(sig_t), n_rec, n_ch, n_s, win_len, step, _tp(sel_t),
+                                                 0 if sel_t is None else n_out, float(thresh), _tp(dist_t), _tp(corr_t),
+                                                 _tp(out.h0), out.h0_cap, _tp(out.c0), _tp(out.h1), out.h1_cap, _tp(out.c1),
+                                                 _tp(out.status), None, _stream()))
+    return out, per_rec
+
+
 def takens_rips_dev(win_t, tau_t, out=None, dim=3, subsample=2, thresh=MAX_EDGE_LENGTH, h1_cap=DEFAULT_H1_CAP,
                     ctx=None):
     import torch

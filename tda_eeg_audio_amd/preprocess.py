@@ -109,6 +109,69 @@ def create_sliding_windows(data, window_size, overlap, fs):
     return windows, times
 
 
+def bandpass_dev(x_t, lowcut, highcut, fs, order=FILTER_ORDER, y_t=None, work_t=None, ctx=None):
+    """apply_bandpass_filter (nb1:236-263) on device tensors: x_t (n_sig, n_samples) float64 -- every channel of every
+    recording of equal length in ONE launch; returns y_t (same shape).  work_t: optional (n_sig, n_samples + 2*edge)."""
+    import torch
+    ctx = ctx or get_ctx()
+    assert x_t.is_cuda and x_t.dtype == torch.float64 and x_t.is_contiguous() and x_t.dim() == 2
+    n_sig, n_s = x_t.shape
+    sos, zi, edge = _sos_plan(design_bandpass_filter(lowcut, highcut, fs, order))
+    if n_s <= edge:
+        raise ValueError(f"The length of the input vector x must be greater than padlen, which is {edge}.")
+    if y_t is None:
+        y_t = torch.empty_like(x_t)
+    if work_t is None or work_t.numel() < n_sig * (n_s + 2 * edge):
+        work_t = torch.empty((n_sig, n_s + 2 * edge), dtype=torch.float64, device=x_t.device)
+    ctx.check(ctx.lib.tda_sosfiltfilt_dev(ctx.h, C.c_void_p(x_t.data_ptr()), n_sig, n_s, ptr(sos), ptr(zi), sos.shape[0], edge,
+                                          C.c_void_p(y_t.data_ptr()), C.c_void_p(work_t.data_ptr()),
+                                          C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    return y_t
+
+
+def recordings_to_features(raw_t, fs, sel_t=None, n_sel_per_rec=None, freq_bands=FREQ_BANDS, window_size=WINDOW_SIZE_SEC,
+                           overlap=OVERLAP_PERCENT, order=FILTER_ORDER, ctx=None):
+    """The EEG half of the corpus from RAW recordings, on the GPU end to end (preprocess_file nb1:388-494 +
+    process_file_graphs nb2:158-218 + the hot loop and aggregation of process_file_features v2:404-436):
+    raw_t (n_rec, n_ch, n_samples) float64 in HBM, recordings of equal length -> per band: zero-phase band-pass of
+    all n_rec * n_ch channels in one launch -> fused window kernel on the sliding windows read in place (the
+    (n_win, n_ch, 250) stacks and the distance matrices never exist) -> H1 row order + extract_features -> mean / std
+    over each recording's windows.  sel_t: optional int32 window list (r * n_win_per_rec + k, n_sel_per_rec per
+    recording, recording-major) -- the drivers' window selection.  Returns (n_rec, 44 * n_bands) float64 tensor in the
+    column order of features/feature_names.txt, and the status words of the last band."""
+    import torch
+    from . import engine
+    ctx = ctx or get_ctx()
+    n_rec, n_ch, n_s = raw_t.shape
+    win = int(window_size * fs)
+    step = int(win * (1 - overlap))
+    per_rec = (n_s - win) // step + 1 if n_s >= win else 0
+    k = per_rec if sel_t is None else int(n_sel_per_rec)
+    n_out = n_rec * k
+    dev = raw_t.device
+    flat = raw_t.view(n_rec * n_ch, n_s)
+    y = torch.empty_like(flat)
+    work = None
+    dgm = engine.DeviceDiagrams(n_out, n_ch, engine.DEFAULT_H1_CAP, dev)
+    fe0 = torch.empty((n_out, 11), dtype=torch.float64, device=dev)
+    fe1 = torch.empty_like(fe0)
+    seg = torch.arange(0, n_out + 1, k, dtype=torch.int32, device=dev)
+    X = torch.empty((n_rec, len(freq_bands), 44), dtype=torch.float64, device=dev)
+    ctx.set_h1_order(ctx.ORDER_DEFERRED)
+    try:
+        for bi, (name, (lo, hi)) in enumerate(freq_bands.items()):
+            sos, zi, edge = _sos_plan(design_bandpass_filter(lo, hi, fs, order))
+            if work is None:
+                work = torch.empty((n_rec * n_ch, n_s + 2 * edge + 64), dtype=torch.float64, device=dev)
+            bandpass_dev(flat, lo, hi, fs, order, y_t=y, work_t=work, ctx=ctx)
+            engine.eeg_window_sliding_dev(y.view(n_rec, n_ch, n_s), win, step, sel_t=sel_t, out=dgm, ctx=ctx)
+            engine.diagram_finish_dev([(dgm.h0, dgm.c0, False, fe0), (dgm.h1, dgm.c1, True, fe1)], ctx=ctx)
+            X[:, bi].copy_(engine.aggregate_dev(fe0, fe1, seg, ctx=ctx))
+    finally:
+        ctx.set_h1_order(ctx.ORDER_IN_CALL)
+    return X.view(n_rec, len(freq_bands) * 44), dgm.status
+
+
 def eeg_to_distances(eeg, fs, freq_bands=FREQ_BANDS, window_size=WINDOW_SIZE_SEC, overlap=OVERLAP_PERCENT,
                      order=FILTER_ORDER, want_corr=False, ctx=None):
     """raw EEG (n_ch, n_samples) -> {band: (n_win, n_ch, n_ch) distance matrices}; everything between the

@@ -87,3 +87,44 @@ def test_audio_front_end_vs_scipy(ctx):
         ref_band = signal.filtfilt(bb, aa, got_env)
         assert wins[name].shape == (n_win, 250)
         assert np.array_equal(wins[name][0], ref_band[:250]) and np.array_equal(wins[name][-1], ref_band[(n_win - 1) * 62:(n_win - 1) * 62 + 250])
+
+
+def test_fused_sliding_windows_equal_stacked_windows(ctx):
+    """tda_eeg_window_sliding_dev: windows read in place from (n_rec, 47, L) band-passed recordings == the same kernel
+    on the materialised (n_win, 47, 250) stack (nb1:314-381), with and without a window selection; and the whole
+    front end, raw EEG -> zero-phase band-pass of all recordings in one launch -> fused sliding kernel, against
+    scipy's sosfiltfilt + the oracle."""
+    import torch
+    from oracle import brute, port
+    from tda_eeg_audio_amd import engine, preprocess
+    dev = torch.device("cuda", ctx.device)
+    rng = np.random.default_rng(21)
+    n_rec, L = 5, 1200
+    raw = rng.standard_normal((n_rec, 47, L)) + 0.4 * rng.standard_normal((n_rec, 1, L))
+    sig_t = torch.from_numpy(raw).to(dev)
+    per_rec = (L - 250) // 62 + 1
+    stack = np.stack([raw[r][:, k * 62:k * 62 + 250] for r in range(n_rec) for k in range(per_rec)])
+    ref = engine.eeg_window_dev(torch.from_numpy(stack).to(dev), ctx=ctx)
+    out, got_per_rec = engine.eeg_window_sliding_dev(sig_t, ctx=ctx)
+    torch.cuda.synchronize()
+    assert got_per_rec == per_rec == 16 and out.n_win == n_rec * per_rec
+    assert torch.equal(out.c0, ref.c0) and torch.equal(out.c1, ref.c1) and int(out.status.max()) == 0
+    a0, a1 = out.to_lists(); b0, b1 = ref.to_lists()
+    assert all(np.array_equal(x, y) for x, y in zip(a0, b0)) and all(np.array_equal(x, y) for x, y in zip(a1, b1))
+    sel = np.array([3, 0, 17, 31, 79, 64, 65], np.int32)            # any order, any recording
+    dist = torch.empty((len(sel), 47, 47), dtype=torch.float64, device=dev)
+    pick, _ = engine.eeg_window_sliding_dev(sig_t, sel_t=torch.from_numpy(sel).to(dev), dist_t=dist, ctx=ctx)
+    p0, p1 = pick.to_lists()
+    for j, g in enumerate(sel):
+        assert np.array_equal(p0[j], b0[g]) and np.array_equal(p1[j], b1[g])
+        assert np.array_equal(dist[j].cpu().numpy(), port.corr_dist(stack[g])[1])
+    # raw -> band-pass (all recordings, one launch) -> fused sliding kernel, against scipy + oracle
+    sos = preprocess.design_bandpass_filter(8, 13, 250)
+    filt = preprocess.sosfiltfilt(sos, raw.reshape(n_rec * 47, L), ctx=ctx).reshape(n_rec, 47, L)
+    assert np.array_equal(filt, signal.sosfiltfilt(sos, raw, axis=-1))
+    out2, _ = engine.eeg_window_sliding_dev(torch.from_numpy(filt).to(dev), ctx=ctx)
+    f0, f1 = out2.to_lists()
+    for g in (0, 15, 16, 47, 79):
+        r, k = divmod(g, per_rec)
+        o = port.rips_dm(port.corr_dist(filt[r][:, k * 62:k * 62 + 250])[1])
+        assert np.array_equal(brute.sort_rows(f0[g]), brute.sort_rows(o[0])) and np.array_equal(brute.sort_rows(f1[g]), brute.sort_rows(o[1]))
