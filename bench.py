@@ -333,6 +333,19 @@ def main():
                                  "same launch on its stream, band batches alone (eager warm-up pass)"},
             "roofline_lds": prof("r02_lds_roofline.json"),
         }
+        fp = extras.get("features_pass")
+        if fp:                                   # secondary: the one HBM-streaming kernel of the step
+            nw, ms = fp.pop("eeg_kernel_windows"), fp.pop("eeg_kernel_ms")
+            ach = ALG_BYTES["eeg_fused"] * nw / (ms * 1e-3) / 1e9
+            tre = tr.get("eeg_window")
+            line["roofline_hbm_kernel"] = {
+                "kernel": "eeg_window_kernel<3, true, 1, false> (fused EEG window: samples -> corr -> dist -> Rips)",
+                "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                "event_ms": round(ms, 4), "windows_per_launch": nw, "alg_bytes_per_launch": ALG_BYTES["eeg_fused"] * nw,
+                "traffic": int(round(tre * nw / tr["_windows_per_launch"])) if tre and tr.get("_windows_per_launch") else None,
+                "note": "secondary: the kernel that streams the corpus (95.1 KB per window, SURVEY.md section 8d); HIP "
+                        "events around one launch of the EEG-only features leg, nothing else on the GPU.  Its time is "
+                        "the Rips sweep behind the fetch, not the fetch"}
         line.update(extras)
         if not args.no_cpu:
             line["cpu_baseline"] = cpu_baseline(eeg, aud, wpr if uniform else 15, args.cpu_seconds)
@@ -366,6 +379,12 @@ def features_leg(args, ctx, device, mine, shards, n_rec, rank, world, nb):
         return tdist.all_gather_rows(flat, mine, shards, n_rec) if world > 1 else flat
     X = one_pass()
     torch.cuda.synchronize()
+    # the fused EEG kernel alone (nothing else on the GPU): HIP events around its first-pass launch on its stream
+    evs = (ctx.new_event(), ctx.new_event())
+    ctx.arm_probe("rips_eeg", evs[0], evs[1])
+    pipeline.run_features_step(eeg[nb - 2], ws, ctx=ctx)
+    torch.cuda.synchronize()
+    eeg_kernel_ms = ctx.elapsed_ms(*evs)
     if world > 1:
         dist.barrier()
     t0 = time.perf_counter()
@@ -388,7 +407,8 @@ def features_leg(args, ctx, device, mine, shards, n_rec, rank, world, nb):
                         f"({n_rec}, {nb * 44}) feature matrix, one all-gather per pass",
             "value": total * args.features_steps / dt, "unit": "windows/s", "steps": args.features_steps,
             "ms_per_step": dt / args.features_steps * 1e3, "matrix_shape": list(X.shape),
-            "matrix_finite": bool(torch.isfinite(X).all().item()), "windows_bad_status": bad}
+            "matrix_finite": bool(torch.isfinite(X).all().item()), "windows_bad_status": bad,
+            "eeg_kernel_ms": eeg_kernel_ms, "eeg_kernel_windows": int(n_win)}
 
 
 def pcie_leg(ctx, device, eeg_b, aud_b, wpr, n_rec=256):
