@@ -17,6 +17,7 @@
 // 64 signals per workgroup.  Samples move through a 64 x 64 LDS tile so that HBM is read and written
 // in rows (coalesced) while each lane walks its own row of the tile.
 #include "common.h"
+#include <stdlib.h>
 
 #define FT 64            // tile: FT signals x FT samples
 #define FTP (FT + 1)     // padded row (doubles): lane-per-row walks are bank-conflict free
@@ -135,6 +136,91 @@ zero_phase_kernel(const double* __restrict__ x, int n_sig, int L, int edge, PARA
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// The second-order-section cascade with its sections PIPELINED across lanes: LPS lanes per signal (LPS = the number
+// of sections rounded up to a power of two), lane s runs section s one sample behind lane s-1 and takes its input
+// from that lane's previous output over the DPP network (row_shr:1).  Every section executes scipy's recursion
+// unchanged and in the same order for its own samples, so the output stays bit-identical to sosfiltfilt; what
+// changes is the dependent chain per sample -- one section instead of the whole cascade -- and the number of
+// waves: 64 / LPS signals per wave instead of 64 (the 16,638 channels of 354 recordings: 1,040 waves instead of
+// 260, on 1,024 SIMDs).  Sections beyond n_sec are the identity (b0 = 1, everything else 0: x_new = 1 * x + 0).
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double dpp_row_shr1_f64(double v)
+{
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x111, 0xF, 0xF, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x111, 0xF, 0xF, true);
+    return __hiloint2double(hi, lo);
+}
+
+template <int LPS>
+__global__ void __launch_bounds__(64)
+sos_pipe_kernel(const double* __restrict__ x, int n_sig, int L, int edge, SosParams p, double* __restrict__ y,
+                double* __restrict__ work)
+{
+    constexpr int SPW = 64 / LPS;                      // signals per wave
+    __shared__ double tin[SPW * FTP], tout[SPW * FTP];
+    __shared__ double coef[F_MAX_SEC][8];              // b0 b1 b2 a0 a1 a2 zi0 zi1 per section (identity beyond n_sec)
+    const int lane = threadIdx.x, sl = lane / LPS, s = lane % LPS;
+    const int s0 = blockIdx.x * SPW, sig = s0 + sl;
+    const int N = L + 2 * edge;
+    const bool live = sig < n_sig;
+    if (lane < F_MAX_SEC * 8) {
+        const int q = lane >> 3, k = lane & 7;
+        double v = (k == 0) ? 1.0 : 0.0;
+        if (q < p.n_sec) v = k < 6 ? p.c[q][k] : p.zi[q][k - 6];
+        coef[q][k] = v;
+    }
+    __syncthreads();
+    const double b0 = coef[s][0], b1 = coef[s][1], b2 = coef[s][2], a1 = coef[s][4], a2 = coef[s][5];
+    const double zi0 = coef[s][6], zi1 = coef[s][7];
+    for (int pass = 0; pass < 2; ++pass) {
+        // pass 0: forward over the odd extension -> work (n_sig, N); pass 1: backward over work -> y (trimmed)
+        double x0 = 0.0;
+        if (live) x0 = pass == 0 ? odd_ext_at(x + (size_t)sig * L, L, edge, 0) : work[(size_t)sig * N + N - 1];
+        double z0 = zi0 * x0, z1 = zi1 * x0;            // sosfilt_zi * first input sample, every section
+        double outp = 0.0;                              // this lane's output of the previous step
+        for (int c0 = 0; c0 < N + LPS - 1; c0 += FT) {
+            // input chunk: positions c0 .. c0+63 of the pass (lane = position: coalesced rows)
+            for (int r = 0; r < SPW; ++r) {
+                const int j = c0 + lane;
+                double v = 0.0;
+                if (s0 + r < n_sig && j < N)
+                    v = pass == 0 ? odd_ext_at(x + (size_t)(s0 + r) * L, L, edge, j) : work[(size_t)(s0 + r) * N + (N - 1 - j)];
+                tin[r * FTP + lane] = v;
+            }
+            __syncthreads();
+            for (int t = 0; t < FT; ++t) {
+                const int i = c0 + t - s;               // position this lane works on in this step
+                const double from_prev = dpp_row_shr1_f64(outp);
+                const double x_cur = s == 0 ? tin[sl * FTP + t] : from_prev;
+                if (i >= 0 && i < N) {
+                    // scipy/signal/_sosfilt.pyx: x_new = b0*x + z0; z0 = (b1*x - a1*x_new + z1); z1 = (b2*x - a2*x_new)
+                    const double x_new = b0 * x_cur + z0;
+                    z0 = (b1 * x_cur - a1 * x_new) + z1;
+                    z1 = b2 * x_cur - a2 * x_new;
+                    outp = x_new;
+                }
+                if (s == LPS - 1) tout[sl * FTP + t] = outp;        // position c0 + t - (LPS - 1) of the output
+            }
+            __syncthreads();
+            for (int r = 0; r < SPW; ++r) {
+                const int j = c0 + lane - (LPS - 1);                // output position of the pass
+                if (s0 + r < n_sig && j >= 0 && j < N) {
+                    const double v = tout[r * FTP + lane];
+                    if (pass == 0) work[(size_t)(s0 + r) * N + j] = v;
+                    else {
+                        const int i = N - 1 - j;                    // index in the padded signal
+                        if (i >= edge && i < edge + L) y[(size_t)(s0 + r) * L + i - edge] = v;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+        __threadfence_block();
+        __syncthreads();                                // work complete (this workgroup's rows) before the backward pass
+    }
+}
+
 tda_status launch_sosfiltfilt(tda_ctx* ctx, const double* x, int n_sig, int L, const double* sos, const double* zi,
                               int n_sec, int edge, double* y, double* work, hipStream_t st)
 {
@@ -147,8 +233,18 @@ tda_status launch_sosfiltfilt(tda_ctx* ctx, const double* x, int n_sig, int L, c
         for (int k = 0; k < 6; ++k) p.c[s][k] = sos[s * 6 + k];
         p.zi[s][0] = zi[s * 2]; p.zi[s][1] = zi[s * 2 + 1];
     }
-    hipLaunchKernelGGL((zero_phase_kernel<SosFilter, SosParams>), dim3((n_sig + FT - 1) / FT), dim3(FT), 0, st, x, n_sig,
-                       L, edge, p, y, work);
+    // sections pipelined across lanes (bit-identical; see sos_pipe_kernel).  TDA_SOS_SERIAL=1: the one-lane-per-signal
+    // form, kept for measurements
+    static const bool serial = getenv("TDA_SOS_SERIAL") != nullptr;
+    if (serial)
+        hipLaunchKernelGGL((zero_phase_kernel<SosFilter, SosParams>), dim3((n_sig + FT - 1) / FT), dim3(FT), 0, st, x, n_sig,
+                           L, edge, p, y, work);
+    else if (n_sec <= 2)
+        hipLaunchKernelGGL(sos_pipe_kernel<2>, dim3((n_sig + 31) / 32), dim3(64), 0, st, x, n_sig, L, edge, p, y, work);
+    else if (n_sec <= 4)
+        hipLaunchKernelGGL(sos_pipe_kernel<4>, dim3((n_sig + 15) / 16), dim3(64), 0, st, x, n_sig, L, edge, p, y, work);
+    else
+        hipLaunchKernelGGL(sos_pipe_kernel<8>, dim3((n_sig + 7) / 8), dim3(64), 0, st, x, n_sig, L, edge, p, y, work);
     TDA_HIP(ctx, hipGetLastError());
     return TDA_OK;
 }
