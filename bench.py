@@ -339,13 +339,16 @@ def main():
             ach = ALG_BYTES["eeg_fused"] * nw / (ms * 1e-3) / 1e9
             tre = tr.get("eeg_window")
             line["roofline_hbm_kernel"] = {
-                "kernel": "eeg_window_kernel<3, true, 1, false> (fused EEG window: samples -> corr -> dist -> Rips)",
+                "kernel": "eeg_window_kernel<3, false, 1, false> (fused EEG window: samples -> corr -> dist -> Rips)",
                 "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                 "event_ms": round(ms, 4), "windows_per_launch": nw, "alg_bytes_per_launch": ALG_BYTES["eeg_fused"] * nw,
                 "traffic": int(round(tre * nw / tr["_windows_per_launch"])) if tre and tr.get("_windows_per_launch") else None,
                 "note": "secondary: the kernel that streams the corpus (95.1 KB per window, SURVEY.md section 8d); HIP "
                         "events around one launch of the EEG-only features leg, nothing else on the GPU.  Its time is "
-                        "the Rips sweep behind the fetch, not the fetch"}
+                        "the Rips sweep behind the fetch, not the fetch.  traffic: the window is fetched twice (means, then "
+                        "products); the second fetch misses L2 and is counted by FETCH_SIZE, but the windows in flight (96 MB) "
+                        "sit in the 256 MiB Infinity Cache, which the counter does not tell from HBM; TDA_EEG_RESIDENT=1 "
+                        "keeps the window in registers instead (one fetch, 11 % slower on this leg)"}
         line.update(extras)
         if not args.no_cpu:
             line["cpu_baseline"] = cpu_baseline(eeg, aud, wpr if uniform else 15, args.cpu_seconds)

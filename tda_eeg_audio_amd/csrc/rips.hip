@@ -1841,11 +1841,13 @@ static tda_status launch_eeg_source(tda_ctx* ctx, const WindowSource& src, int n
     if (n_t < 2 || n_t > CD_RES_CHUNKS * CD_TCH) TDA_FAIL(ctx, TDA_ERR_UNSUPPORTED, "the fused EEG kernel takes windows of 2..256 samples (the reference has 250)");
     if (h0_cap < n_ch) TDA_FAIL(ctx, TDA_ERR_INVALID, "h0_cap must be >= n_ch");
     RipsOut out{h0, h0_cap, h0_cnt, h1, h1_cap, h1_cnt, status};
-    // The window stays in registers between the two passes over it (means, then centred products): ONE HBM read,
-    // 148 VGPRs, three workgroups per CU.  The streaming form (window fetched twice: 128 VGPRs, four per CU) measured
-    // 2 % faster on the EEG-only pass and the same end to end, but its second fetch shows up at the memory side
-    // (FETCH_SIZE 181 KB per window against 95 KB algorithmic); it stays available for measurements: TDA_EEG_STREAM=1
-    static const bool stream_twice = getenv("TDA_EEG_STREAM") != nullptr;
+    // The window is fetched twice (means, then centred products): 128 VGPRs, four workgroups per CU.  The second
+    // fetch misses the 4 MB L2 of the XCD (128 windows in flight there) and shows in FETCH_SIZE (181 KB per window
+    // against 95 KB algorithmic), but the windows in flight on the whole chip are 96 MB, inside the 256 MiB Infinity
+    // Cache, which that counter does not tell from HBM.  Keeping the window in registers between the passes instead
+    // (one fetch, 148 VGPRs, three workgroups per CU) measured 11 % slower on the EEG-only pass and 2 % end to end;
+    // it stays available: TDA_EEG_RESIDENT=1
+    static const bool stream_twice = getenv("TDA_EEG_RESIDENT") == nullptr;
     const tda_status rc = stream_twice ? launch_eeg_ladder<false>(ctx, src, n_win, n_ch, n_t, (float)thresh, out, dist, corr, st)
                                        : launch_eeg_ladder<true>(ctx, src, n_win, n_ch, n_t, (float)thresh, out, dist, corr, st);
     if (rc != TDA_OK) return rc;

@@ -71,6 +71,6 @@ def roof(kname_part):
 lds = {"bound": "lds/issue", "unit": "B/clk/CU", "peak": 128.0,
        "source": f"profiles/{tag}_sq_counters.json (rocprofv3 --pmc, tools/collect_profiles.sh)",
        "rips_cloud": roof("rips_cloud_kernel<512, 1, unsigned int, false"), "rips_dm": roof("rips_dm_kernel<256, 1, 1"),
-       "eeg_fused": roof("eeg_window_kernel<3, true, 1, false")}
+       "eeg_fused": roof("eeg_window_kernel<3, false, 1, false")}
 json.dump(lds, open(os.path.join(out, f"{tag}_lds_roofline.json"), "w"), indent=1)
 print(json.dumps(lds, indent=1))

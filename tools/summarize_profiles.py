@@ -50,7 +50,7 @@ for d, ctr in (("prof_fetch", "FETCH_SIZE"), ("prof_write", "WRITE_SIZE")):
 json.dump(pmc, open(os.path.join(out, f"{tag}_pmc_summary.json"), "w"), indent=1)
 
 STAGE_KERNEL = {
-    "eeg_window": "eeg_window_kernel<3, true, 1, false", "corr_dist": "corr_dist_kernel",
+    "eeg_window": "eeg_window_kernel<3, false, 1, false", "corr_dist": "corr_dist_kernel",
     "rips_eeg": "rips_dm_kernel<256, 1, 1, unsigned long long, false", "rips_audio": "rips_cloud_kernel<512, 1, unsigned int, false",
     "wasserstein_h0": "wasserstein_kernel<2", "wasserstein_h1": "wasserstein_kernel<4", "tau": "tau_kernel",
     "finish": "diagram_finish_kernel",
