@@ -699,3 +699,36 @@ def test_recording_rows_skip_degenerate_audio_windows(ctx):
         for f in range(11):                     # v2:429-436: np.mean / np.std of the list of per-window values
             assert got[s, 4 + 4 * f] == np.mean(list(f0[a:b, f])) and got[s, 7 + 4 * f] == np.std(list(f1[a:b, f]))
     assert np.isnan(got[2, :2]).all()
+
+
+def test_ranking_degenerate_key_distributions(ctx):
+    """The bucket ranking of the Rips kernels on the distributions that defeat a linear bucket map: every edge the same
+    length (one bucket holds all E edges: the quadratic fallback), all lengths zero (duplicate points: the map's scale
+    is infinite), two values only, one outlier that stretches the range, and a NaN entry (must not hang; the edge is
+    dropped like one beyond the threshold)."""
+    rng = np.random.default_rng(12)
+    cases = []
+    for n in (47, 128):
+        d = np.full((n, n), 1.0); np.fill_diagonal(d, 0.0); cases.append(("equal", d))
+        cases.append(("zero", np.zeros((n, n))))
+        d = np.where(rng.random((n, n)) < 0.5, 0.5, 1.5); d = np.minimum(d, d.T); np.fill_diagonal(d, 0.0); cases.append(("two", d))
+        if n == 47:                      # (a random metric on 128 points needs more classes than the n > 64 ladder holds)
+            d = rng.random((n, n)) * 1e-3 + 1e-3; d = np.minimum(d, d.T); d[0, 1] = d[1, 0] = 1.9; np.fill_diagonal(d, 0.0)
+            cases.append(("outlier", d))
+    for name, d in cases:
+        h0, h1, st = engine.rips_dm_batch(d[None], thresh=2.0, h1_cap=4096, ctx=ctx)
+        o = port.rips_dm(d, thresh=2.0)
+        assert st[0] == 0 and _same_multiset(h0[0], o[0]) and _same_multiset(h1[0], o[1]), (name, d.shape)
+    # point clouds: all points identical; points on a line with equal spacing (massive ties)
+    for pc in (np.ones((60, 3)), np.stack([np.arange(90.0), np.zeros(90), np.zeros(90)], 1)):
+        h0, h1, st = engine.cloud_rips_batch(pc[None], normalise=True, thresh=2.0, h1_cap=4096, ctx=ctx)
+        o = port.rips_f32(port.cloud_dm(port.minmax_normalise(pc)).astype(np.float32), thresh=2.0)
+        assert (st[0] & ~4) == 0 and _same_multiset(h0[0], o[0]) and _same_multiset(h1[0], o[1])
+    # NaN: no hang, the other windows of the batch are untouched
+    W = port.corr_dist_batch(synth.eeg_windows(3, seed=4))[1]
+    W[1, 5, 9] = W[1, 9, 5] = np.nan
+    h0, h1, st = engine.rips_dm_batch(W, ctx=ctx)
+    for w in (0, 2):
+        o = port.rips_dm(W[w])
+        assert st[w] == 0 and _same_multiset(h0[w], o[0]) and _same_multiset(h1[w], o[1])
+    assert len(h0[1]) >= 1
