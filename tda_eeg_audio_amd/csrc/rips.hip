@@ -1206,7 +1206,7 @@ __device__ void rips_sweep(int n, int E, int Ev, const u16* rank, const u16* ord
             atomicOr(reinterpret_cast<unsigned long long*>(&adj[2 * b + (a >> 6)]), 1ull << (a & 63));
         }
         if (tid < 256) adjc[tid] = 0ull;
-        if (tid == 0) { lcnt[0] = 0u; lcnt[1] = 0xffffffffu; }
+        if (tid == 0) { lcnt[0] = 0u; lcnt[1] = 0xffffffffu; shared->clen = 0x7fffffff; }
         __syncthreads();
         // The end of the story: no class is alive and EVERY remaining edge already has a common neighbour, now and
         // (adjacency only grows) at its own time.  Then no remaining edge is a candidate: no component can merge,
@@ -1227,7 +1227,28 @@ __device__ void rips_sweep(int n, int E, int Ev, const u16* rank, const u16* ord
                 rr += NT;
             }
             cov_next = rr;
-            if (wg_all<NT>(vote, covered)) { PROF_COUNT(25, 1); PROF_MARK(7); break; }
+            // the FIRST edge without a common neighbour, over the whole workgroup (every residue class stopped at its
+            // own first one): nothing can happen before it
+            {
+                const u32 wmin = wave_min_u32_dpp(covered ? 0x7fffffffu : (u32)rr);
+                if (lane == 0 && wmin != 0x7fffffffu) atomicMin(reinterpret_cast<unsigned int*>(&shared->clen), wmin);
+            }
+            __syncthreads();
+            const int ru = shared->clen;
+            if (ru >= Ev) { PROF_COUNT(25, 1); PROF_MARK(7); break; }
+            // ... so the edges up to it only join the adjacency rows, and the next chunk starts AT it: whole chunks of
+            // the long-edge tail that hold no candidate are never swept
+            if (ru > from) {
+                for (int r2 = from + tid; r2 < ru; r2 += NT) {
+                    const u32 pk = ord[r2];
+                    const int ea = (int)(pk >> 8), eb = (int)(pk & 255u);
+                    atomicOr(reinterpret_cast<unsigned long long*>(&adj[2 * ea + (eb >> 6)]), 1ull << (eb & 63));
+                    atomicOr(reinterpret_cast<unsigned long long*>(&adj[2 * eb + (ea >> 6)]), 1ull << (ea & 63));
+                }
+                PROF_COUNT(35, ru - from);
+                clen = ru - r0;                                  // (the loop advances r0 by clen)
+                __syncthreads();
+            }
         }
         PROF_MARK(7);
     }
