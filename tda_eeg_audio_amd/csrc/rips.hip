@@ -249,38 +249,32 @@ struct Bucketer {
 // stays one: H0 is connected, every H1 class is dead and every later edge is killed at once by the
 // apex with zero persistence.  Edges longer than r_enc therefore cannot contribute a diagram row
 // (ripser applies the same cut when no threshold is given); dropping them shortens the sweep.
-// vmax[v] (u32 sortable keys, LDS) must hold max_u key(v,u) on entry.  Returns the number of edges
-// whose key is <= the effective threshold (workgroup-uniform); teff_out / kmin_out: that threshold and the
-// smallest key of the window.  red: u32[4] scratch in LDS.
+// vmax[v] (u32 sortable keys, LDS) must hold max_u key(v,u) on entry.  teff_out / kmin_out: the effective threshold and
+// the smallest key of the window (kmin_thread: the minimum over the keys this thread produced).  The number of edges
+// within the threshold falls out of the ranking (rank_edges returns it).  red: u32[4] scratch in LDS.
 template <int NT>
-__device__ int count_effective_edges(const u32* key32, int E, int n, u32 tkey, const u32* vmax, u32* red, u32& teff_out,
-                                     u32& kmin_out)
+__device__ void effective_threshold(int n, u32 tkey, const u32* vmax, u32 kmin_thread, u32* red, u32& teff_out, u32& kmin_out)
 {
     const int tid = threadIdx.x;
     // enclosing radius: every wave takes the minimum over the (<= 128) vertices, two per lane, on the DPP network
     const int lane = tid & 63;
     const u32 m0 = lane < n ? vmax[lane] : 0xffffffffu, m1 = lane + 64 < n ? vmax[lane + 64] : 0xffffffffu;
     const u32 renc = wave_min_u32_dpp(m0 < m1 ? m0 : m1);
-    const u32 teff = renc < tkey ? renc : tkey;
-    int ev = 0;
-    u32 kmin = 0xffffffffu;
-    for (int e = tid; e < E; e += NT) { const u32 k = key32[e]; ev += (k <= teff) ? 1 : 0; kmin = k < kmin ? k : kmin; }
-    if (tid == 0) { red[0] = 0u; red[1] = 0xffffffffu; }
+    teff_out = renc < tkey ? renc : tkey;
+    // smallest key of the window: every thread brings the minimum over the keys it produced
+    if (tid == 0) red[1] = 0xffffffffu;
     __syncthreads();
-    ev = wave_incl_scan_i32(ev);                      // lane 63 holds the wave's sum
-    kmin = wave_min_u32_dpp(kmin);
-    if (lane == 63) { atomicAdd(&red[0], (u32)ev); atomicMin(&red[1], kmin); }
+    const u32 kmin = wave_min_u32_dpp(kmin_thread);
+    if (lane == 63) atomicMin(&red[1], kmin);
     __syncthreads();
-    teff_out = teff;
     kmin_out = red[1];
-    return (int)red[0];
 }
 
 // key32: E keys (flat index order).  members: E u16 (may share its LDS with ord).  cursor: NB u16 (as NB/2 packed
 // words).  wsum: NT/64 ints.
 template <int NT, int NB, bool WANT_KEYS>
-__device__ void rank_edges(const u32* key32, int E, u32 teff, u32 kmin, u16* members, u32* cursor, int* wsum, u16* rank,
-                           u16* ord, u32* skey)
+__device__ int rank_edges(const u32* key32, int E, u32 teff, u32 kmin, u16* members, u32* cursor, int* wsum, u16* rank,
+                          u16* ord, u32* skey)
 {
     static_assert(NB % (2 * NT) == 0, "every thread scans whole words");
     constexpr int WPT = NB / NT / 2;                  // packed words per thread in the scan
@@ -291,10 +285,13 @@ __device__ void rank_edges(const u32* key32, int E, u32 teff, u32 kmin, u16* mem
     bk.scale = bk.top / (sortable_f32(teff) - bk.dmin);
     for (int i = tid; i < NB / 2; i += NT) cursor[i] = 0u;
     __syncthreads();
-    // ---- count ----
+    // ---- count (the bucket of every edge waits in its slot of the rank table: computed once) ----
+#pragma unroll 4
     for (int e = tid; e < E; e += NT) {
         const u32 k = key32[e];
-        if (k <= teff) { const int b = bk(k); atomicAdd(&cursor[b >> 1], 1u << (16 * (b & 1))); }
+        u32 b = 0xffffu;
+        if (k <= teff) { b = (u32)bk(k); atomicAdd(&cursor[b >> 1], 1u << (16 * (b & 1))); }
+        rank[e] = (u16)b;
     }
     __syncthreads();
     // ---- scan ----
@@ -319,10 +316,11 @@ __device__ void rank_edges(const u32* key32, int E, u32 teff, u32 kmin, u16* mem
     }
     __syncthreads();
     // ---- scatter: afterwards cursor[b] = end of bucket b = start of bucket b + 1 ----
+#pragma unroll 4
     for (int e = tid; e < E; e += NT) {
-        const u32 k = key32[e];
-        if (k <= teff) {
-            const int b = bk(k), sh = 16 * (b & 1);
+        const u32 b = rank[e];
+        if (b != 0xffffu) {
+            const int sh = 16 * (int)(b & 1u);
             const u32 old = atomicAdd(&cursor[b >> 1], 1u << sh);
             members[(old >> sh) & 0xffffu] = (u16)e;
         }
@@ -330,11 +328,13 @@ __device__ void rank_edges(const u32* key32, int E, u32 teff, u32 kmin, u16* mem
     __syncthreads();
     // ---- rank ----
     const u16* cur16 = reinterpret_cast<const u16*>(cursor);
+    const int Ev = (int)cur16[NB - 1];                // end of the last bucket = edges within the effective threshold
+#pragma unroll 4
     for (int e = tid; e < E; e += NT) {
-        const u32 k = key32[e];
+        const u32 b = rank[e];
         u32 r = RANK_NONE;
-        if (k <= teff) {
-            const int b = bk(k);
+        if (b != 0xffffu) {
+            const u32 k = key32[e];
             const int lo = b ? (int)cur16[b - 1] : 0, hi = (int)cur16[b];
             int c = 0;
             for (int j = lo; j < hi; ++j) {
@@ -348,6 +348,7 @@ __device__ void rank_edges(const u32* key32, int E, u32 teff, u32 kmin, u16* mem
     }
     __syncthreads();                                  // ord may overlay `members`: every read of it is done
     // ---- ord (and the sorted keys) from the rank table ----
+#pragma unroll 4
     for (int e = tid; e < E; e += NT) {
         const u32 r = rank[e];
         if (r != RANK_NONE) {
@@ -357,6 +358,7 @@ __device__ void rank_edges(const u32* key32, int E, u32 teff, u32 kmin, u16* mem
         }
     }
     __syncthreads();
+    return Ev;
 }
 
 struct RipsOut {
@@ -1282,8 +1284,8 @@ struct KeyFromLds {
 
 // everything after the keys: key32[e] (flat edge order) and vmax[v] = max_u key(v,u) are in LDS, barrier passed
 template <int NT, int NVW, int W, typename WT>
-__device__ void rips_dm_rest(unsigned char* smem, const int win, int n, float thresh, const u32* vmax, const RipsLayout& L,
-                             const RipsOut& out)
+__device__ void rips_dm_rest(unsigned char* smem, const int win, int n, float thresh, const u32* vmax, u32 kmin_thread,
+                             const RipsLayout& L, const RipsOut& out)
 {
     const int tid = threadIdx.x;
     const int E = tri2(n);
@@ -1300,8 +1302,8 @@ __device__ void rips_dm_rest(unsigned char* smem, const int win, int n, float th
     const u32 tkey = f32_sortable(thresh);
     u32 teff, kmin;
     PROF_RESUME();
-    const int Ev = count_effective_edges<NT>(key32, E, n, tkey, vmax, red, teff, kmin);
-    rank_edges<NT, (NVW == 1 ? 2048 : 8192), true>(key32, E, teff, kmin, members, cursor, wsum, rank, ord, skey);
+    effective_threshold<NT>(n, tkey, vmax, kmin_thread, red, teff, kmin);
+    const int Ev = rank_edges<NT, (NVW == 1 ? 2048 : 8192), true>(key32, E, teff, kmin, members, cursor, wsum, rank, ord, skey);
     PROF_MARK(1);
     guard_write(smem, L);
     int k0, k1, st;
@@ -1331,6 +1333,7 @@ __device__ void rips_dm_window(unsigned char* smem, const int win, const double*
     u32* vmax = reinterpret_cast<u32*>(misc + MISC_COMP);
     if (tid < 128) vmax[tid] = 0u;
     __syncthreads();
+    u32 kmin_thread = 0xffffffffu;
     for (int e = tid; e < E; e += NT) {
         const int a = edge_row(e), b = e - tri2(a);
         double v;
@@ -1342,12 +1345,13 @@ __device__ void rips_dm_window(unsigned char* smem, const int win, const double*
         }
         const u32 sk = f32_sortable((float)v);
         key32[e] = sk;
+        kmin_thread = sk < kmin_thread ? sk : kmin_thread;
         atomicMax(&vmax[a], sk);
         atomicMax(&vmax[b], sk);
     }
     __syncthreads();
     PROF_MARK(0);
-    rips_dm_rest<NT, NVW, W, WT>(smem, win, n, thresh, vmax, L, out);
+    rips_dm_rest<NT, NVW, W, WT>(smem, win, n, thresh, vmax, kmin_thread, L, out);
 }
 
 #ifdef TDA_DEBUG_PTS
@@ -1532,20 +1536,22 @@ __device__ void rips_cloud_window(unsigned char* smem, const int win, const doub
     int* wsum = reinterpret_cast<int*>(misc + MISC_WV);
     if (tid < 128) vmax[tid] = 0u;
     __syncthreads();
+    u32 kmin_thread = 0xffffffffu;
     for (int e = tid; e < E; e += NT) {
         const int a = edge_row(e), b = e - tri2(a);
         const u32 sk = f32_sortable(kf(0, a, b));
         key32[e] = sk;
+        kmin_thread = sk < kmin_thread ? sk : kmin_thread;
         atomicMax(&vmax[b], sk);          // (consecutive lanes: consecutive b, no conflict)
     }
     __syncthreads();
     row_maxima<NT>(key32, vmax, P);
     __syncthreads();
     u32 teff, kmin;
-    const int Ev = count_effective_edges<NT>(key32, E, P, tkey, vmax, red, teff, kmin);
+    effective_threshold<NT>(P, tkey, vmax, kmin_thread, red, teff, kmin);
     PROF_MARK(0);
     PROF_STOP(1, if (tid == 0) { out.h0_cnt[win] = 0; out.h1_cnt[win] = 0; out.status[win] = 0; });
-    rank_edges<NT, 8192, false>(key32, E, teff, kmin, members, cursor, wsum, rank, ord, nullptr);
+    const int Ev = rank_edges<NT, 8192, false>(key32, E, teff, kmin, members, cursor, wsum, rank, ord, nullptr);
     PROF_MARK(1);
     PROF_STOP(2, if (tid == 0) { out.h0_cnt[win] = 0; out.h1_cnt[win] = 0; out.status[win] = 0; });
     guard_write(smem, L);
@@ -1656,12 +1662,14 @@ __device__ __forceinline__ void eeg_one_window(unsigned char* smem, const Window
     u32* vmax = reinterpret_cast<u32*>(smem + 4 * ((E + 3) & ~3));
     if (tid < 128) vmax[tid] = 0u;
     __syncthreads();
+    u32 kmin_thread = 0xffffffffu;
     for (int e = tid; e < E; e += 256) {
         const int a = edge_row(e), b = e - tri2(a);
         double v = (dist_at(a, b, nullptr) + dist_at(b, a, nullptr)) / 2.0;      // utils.py:137
         if (v < 0.0) v = 0.0;                                                    // utils.py:139
         const u32 sk = f32_sortable((float)v);
         key32[e] = sk;
+        kmin_thread = sk < kmin_thread ? sk : kmin_thread;
         atomicMax(&vmax[a], sk);
         atomicMax(&vmax[b], sk);
     }
@@ -1678,7 +1686,7 @@ __device__ __forceinline__ void eeg_one_window(unsigned char* smem, const Window
     }
     __syncthreads();
     PROF_MARK(0);
-    rips_dm_rest<256, 1, W, u64>(smem, w, n_ch, thresh, vmax, L, out);
+    rips_dm_rest<256, 1, W, u64>(smem, w, n_ch, thresh, vmax, kmin_thread, L, out);
 }
 
 // RETRY = false: one window per workgroup and NO loop over windows -- with the loop the compiler hoists the address
