@@ -167,10 +167,10 @@ __device__ __forceinline__ int pair_index(int x, int y) { return x > y ? tri2(x)
 // flat edge index e = tri2(a)+b (a > b)  ->  a
 __device__ __forceinline__ int edge_row(int e)
 {
-    int a = (int)((1.0f + sqrtf(1.0f + 8.0f * (float)e)) * 0.5f);
-    while (tri2(a) > e) --a;
-    while (tri2(a + 1) <= e) ++a;
-    return a;
+    // e < 2^13: 1 + 8e is exact in float and the square root is off by at most one ulp, so the estimate is off by at
+    // most one row -- one branch-free correction instead of two search loops
+    const int a = (int)((1.0f + sqrtf(1.0f + 8.0f * (float)e)) * 0.5f);
+    return a + (tri2(a + 1) <= e ? 1 : 0) - (tri2(a) > e ? 1 : 0);
 }
 
 // ---------------------------------------------------------------------------------
@@ -511,6 +511,7 @@ __device__ void rips_sweep(int n, int E, int Ev, const u16* rank, const u16* ord
         for (int w = 0; w < NVW; ++w) many |= M[w];
         const bool is_cand = valid && many == 0;
         PROF_MARK(4);
+        PROF_STOP(11, out_k0 = k0; out_k1 = k1; out_status = 0);
         // ---- b. candidates (edges without a common neighbour): Kruskal in rank order ----
         // Only the union-find itself is sequential: wave 0 walks the candidates with the component labels
         // in registers and leaves one "merge" bit per edge.  Everything that follows from the decision
@@ -529,6 +530,7 @@ __device__ void rips_sweep(int n, int E, int Ev, const u16* rank, const u16* ord
         done[tid] = 0;
         __syncthreads();
         PROF_MARK(21);
+        PROF_STOP(12, out_k0 = k0; out_k1 = k1; out_status = 0);
         int nfree = 0;
 #pragma unroll
         for (int c = 0; c < W; ++c) nfree += __builtin_popcountll((u64)(WT)~alive[c]);
@@ -701,6 +703,7 @@ __device__ void rips_sweep(int n, int E, int Ev, const u16* rank, const u16* ord
         }
         __syncthreads();
         PROF_MARK(22);
+        PROF_STOP(13, out_k0 = k0; out_k1 = k1; out_status = 0);
         clen = offs[19];
         if (clen == 0) status |= TDA_WIN_CLASS_OVERFLOW;      // not even the first edge of the chunk fits
         if (clen < NT) PROF_COUNT(14, 1);
@@ -758,6 +761,7 @@ __device__ void rips_sweep(int n, int E, int Ev, const u16* rank, const u16* ord
         if (status) break;
         if (deferred && btot > 0) confirm();         // a class was born after all: the chunk needs the exact masks
         PROF_MARK(5);
+        PROF_STOP(14, out_k0 = k0; out_k1 = k1; out_status = 0);
         // No class alive and none born in this chunk: every psi entry is zero (dead classes were substituted out,
         // unwritten entries start at zero), so the apparent edges of the chunk get the zero vector they already hold
         // and no triangle can kill anything.  Phases c and d are skipped; only the adjacency rows move on.  This is
@@ -815,6 +819,7 @@ __device__ void rips_sweep(int n, int E, int Ev, const u16* rank, const u16* ord
             }
         }
         PROF_MARK(6);
+        PROF_STOP(15, out_k0 = k0; out_k1 = k1; out_status = 0);
         // ---- d. the other triangles of every apparent edge ----
         // Link argument: if v and v' are common neighbours of (a,b) and adjacent to each other, the
         // tetrahedron (a,b,v,v') shows that triangles (a,b,v) and (a,b,v') carry the same boundary
@@ -882,6 +887,7 @@ __device__ void rips_sweep(int n, int E, int Ev, const u16* rank, const u16* ord
             if (NVW == 2) { m2 = (u32)rem[NVW - 1]; m3 = (u32)(rem[NVW - 1] >> 32); }
         }
         PROF_MARK(16);
+        PROF_STOP(16, out_k0 = k0; out_k1 = k1; out_status = 0);
         // All non-trivial triangles of the chunk are listed under the frozen table (key = lane << 8 | v, the
         // order in which a sequential sweep meets them) and wave 0 reduces the list in registers: the
         // earliest non-zero vector kills the YOUNGEST class in it (elder rule) and is substituted into
@@ -962,6 +968,7 @@ __device__ void rips_sweep(int n, int E, int Ev, const u16* rank, const u16* ord
             }
             __syncthreads();
             PROF_MARK(17);
+            PROF_STOP(17, out_k0 = k0; out_k1 = k1; out_status = 0);
             const u32 cnt = lcnt[0];
             if (cnt == 0u) break;
             const bool complete = cnt <= (u32)LCAP;
@@ -1129,6 +1136,7 @@ __device__ void rips_sweep(int n, int E, int Ev, const u16* rank, const u16* ord
             }
             __syncthreads();
             PROF_MARK(18);
+            PROF_STOP(18, out_k0 = k0; out_k1 = k1; out_status = 0);
             WT kmask[W];
 #pragma unroll
             for (int c = 0; c < W; ++c) { const WT na = (WT)shared->alive[c]; kmask[c] = alive_before[c] & (WT)~na; alive[c] = na; }
@@ -1196,6 +1204,7 @@ __device__ void rips_sweep(int n, int E, int Ev, const u16* rank, const u16* ord
                 }
             }
             PROF_MARK(19);
+            PROF_STOP(19, out_k0 = k0; out_k1 = k1; out_status = 0);
             if (complete && !more) break;
             if (++list_rounds > 4 * NT) { status |= TDA_WIN_CLASS_OVERFLOW; break; }   // every round kills >= 1 class: never reached
             __syncthreads();            // table rewritten before the chunk is listed again

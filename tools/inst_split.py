@@ -16,7 +16,7 @@ for band in ["beta", "delta"]:
     tau = engine.tau_batch(wins[:1].cpu().numpy(), 125, ctx=ctx)[0]
     tau_t = torch.full((NW,), int(tau), dtype=torch.int32, device=dev)
     out = engine.DeviceDiagrams(NW, 128, 256, dev)
-    for stop in (1, 2, 0):
+    for stop in (1, 2, 11, 12, 13, 14, 15, 16, 17, 18, 19, 0):
         lib.tda_profile_stop_after(stop)
         engine.takens_rips_dev(wins, tau_t, out, ctx=ctx); torch.cuda.synchronize()
 lib.tda_profile_stop_after(0)
