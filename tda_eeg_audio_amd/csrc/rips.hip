@@ -1382,6 +1382,14 @@ struct KeyFromPts {
     {
         // sklearn euclidean_distances: -2 x.y + |x|^2 + |y|^2, clamp, sqrt  (see oracle)
         double na = 0.0, nb = 0.0, dot = 0.0;
+        if (dim == 3) {                          // the reference's TAKENS_DIM: the same operations, unrolled
+            const double* pa = pts + 3 * a;
+            const double* pb = pts + 3 * b;
+            const double a0 = pa[0], a1 = pa[1], a2 = pa[2], b0 = pb[0], b1 = pb[1], b2 = pb[2];
+            na = (a0 * a0 + a1 * a1) + a2 * a2;  // (0.0 + a0^2 is a0^2 exactly)
+            nb = (b0 * b0 + b1 * b1) + b2 * b2;
+            dot = fma(a2, b2, fma(a1, b1, a0 * b0));
+        } else
         for (int k = 0; k < dim; ++k) {
             const double xa = pts[a * dim + k], xb = pts[b * dim + k];
             na += xa * xa;
