@@ -65,8 +65,10 @@ void       tda_ctx_destroy(tda_ctx* ctx);
 /* Copies the last error message of this context (or of the failed create when
  * ctx == NULL) into buf; returns its length. */
 size_t     tda_last_error(const tda_ctx* ctx, char* buf, size_t cap);
-/* Capacity for simultaneously alive H1 classes = 64 * words, words in {1,2,4}.
- * Defaults: 2 for distance-matrix input, 1 for point clouds. */
+/* First-pass capacity for simultaneously alive H1 classes.  words_dm in {0,1,2,4}: 64 * words bits for distance-matrix
+ * input; 0 = 32 bits, honoured by the fused EEG window kernel only (tda_rips_dm_batch treats it as 1).  words_cloud in
+ * {1,2}: 32 or 64 bits for point clouds.  Defaults: 2 and 1.  Windows that need more are redone by the widening passes
+ * (tda_set_retry_policy), so the setting changes speed, never results. */
 tda_status tda_set_class_words(tda_ctx* ctx, int words_dm, int words_cloud);
 /* How the Rips entry points treat windows that run out of class bits (TDA_WIN_CLASS_OVERFLOW).
  * AUTO (default): every call launches its widening passes after the first pass; they redo only the flagged

@@ -52,8 +52,8 @@ size_t tda_last_error(const tda_ctx* ctx, char* buf, size_t cap)
 tda_status tda_set_class_words(tda_ctx* ctx, int words_dm, int words_cloud)
 {
     if (!ctx) return TDA_ERR_INVALID;
-    if ((words_dm != 1 && words_dm != 2 && words_dm != 4) || (words_cloud != 1 && words_cloud != 2))
-        TDA_FAIL(ctx, TDA_ERR_INVALID, "class words: dm in {1,2,4}, cloud in {1,2}");
+    if ((words_dm != 0 && words_dm != 1 && words_dm != 2 && words_dm != 4) || (words_cloud != 1 && words_cloud != 2))
+        TDA_FAIL(ctx, TDA_ERR_INVALID, "class words: dm in {0,1,2,4}, cloud in {1,2}");
     ctx->words_dm = words_dm;
     ctx->words_cloud = words_cloud;
     return TDA_OK;

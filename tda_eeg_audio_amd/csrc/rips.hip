@@ -1312,8 +1312,10 @@ __device__ void rips_dm_rest(unsigned char* smem, const int win, int n, float th
     u32 teff, kmin;
     PROF_RESUME();
     effective_threshold<NT>(n, tkey, vmax, kmin_thread, red, teff, kmin);
+    PROF_STOP(1, if (tid == 0) { out.h0_cnt[win] = 0; out.h1_cnt[win] = 0; out.status[win] = 0; });
     const int Ev = rank_edges<NT, (NVW == 1 ? 2048 : 8192), true>(key32, E, teff, kmin, members, cursor, wsum, rank, ord, skey);
     PROF_MARK(1);
+    PROF_STOP(2, if (tid == 0) { out.h0_cnt[win] = 0; out.h1_cnt[win] = 0; out.status[win] = 0; });
     guard_write(smem, L);
     int k0, k1, st;
     KeyFromLds kf{skey};
@@ -1654,7 +1656,7 @@ struct WindowSource {
     }
 };
 
-template <int NB, bool RES, int W>
+template <int NB, bool RES, int W, typename WT>
 __device__ __forceinline__ void eeg_one_window(unsigned char* smem, const WindowSource& src, int w, int n_ch,
                                                int n_t, float thresh, const RipsLayout& L, const RipsOut& out,
                                                double* __restrict__ dist, double* __restrict__ corr)
@@ -1703,7 +1705,7 @@ __device__ __forceinline__ void eeg_one_window(unsigned char* smem, const Window
     }
     __syncthreads();
     PROF_MARK(0);
-    rips_dm_rest<256, 1, W, u64>(smem, w, n_ch, thresh, vmax, kmin_thread, L, out);
+    rips_dm_rest<256, 1, W, WT>(smem, w, n_ch, thresh, vmax, kmin_thread, L, out);
 }
 
 // RETRY = false: one window per workgroup and NO loop over windows -- with the loop the compiler hoists the address
@@ -1713,7 +1715,7 @@ __device__ __forceinline__ void eeg_one_window(unsigned char* smem, const Window
 // (deterministically; tools/dbg_fused.py) while the same source at two waves per SIMD (256 VGPRs, no AGPRs) is
 // exact -- not understood beyond that, so every variant of this kernel stays at >= 2 waves per SIMD and
 // tests/test_gpu_parity.py::test_fused_eeg_window_512_classes covers the widest one.
-template <int NB, bool RES, int W, bool RETRY>
+template <int NB, bool RES, int W, bool RETRY, typename WT>
 __global__ void __launch_bounds__(256, (W > 2 || RETRY) ? 2 : (RES ? 3 : 4))
 eeg_window_kernel(WindowSource windows, int n_win, int n_ch, int n_t, float thresh, RipsLayout L, RipsOut out,
                   double* __restrict__ dist, double* __restrict__ corr, unsigned long long* __restrict__ retry_ctr)
@@ -1721,11 +1723,11 @@ eeg_window_kernel(WindowSource windows, int n_win, int n_ch, int n_t, float thre
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     if constexpr (!RETRY) {
         if ((int)blockIdx.x < n_win)
-            eeg_one_window<NB, RES, W>(smem, windows, (int)blockIdx.x, n_ch, n_t, thresh, L, out, dist, corr);
+            eeg_one_window<NB, RES, W, WT>(smem, windows, (int)blockIdx.x, n_ch, n_t, thresh, L, out, dist, corr);
     } else {
         RETRY_SCAN_BEGIN(256, out.status, n_win)
             if (retry_ctr && threadIdx.x == 0) atomicAdd(retry_ctr, 1ull);
-            eeg_one_window<NB, RES, W>(smem, windows, win, n_ch, n_t, thresh, L, out, dist, corr);
+            eeg_one_window<NB, RES, W, WT>(smem, windows, win, n_ch, n_t, thresh, L, out, dist, corr);
         RETRY_SCAN_END()
     }
 }
@@ -1805,7 +1807,7 @@ tda_status launch_rips_dm(tda_ctx* ctx, const double* dm, int n_win, int n, doub
     RipsOut out{h0, h0_cap, h0_cnt, h1, h1_cap, h1_cnt, status};
     const float th = (float)thresh;
     tda_status rc;
-    int W = ctx->words_dm;
+    int W = ctx->words_dm < 1 ? 1 : ctx->words_dm;      // (32-bit class words exist in the fused EEG kernel only)
     // largest class capacity that still fits the 160 KiB LDS
     while (W > 1 && make_layout(n, W * 8, n * (n - 1) / 2 * 4, 256).total > LDS_MAX) W >>= 1;
     const bool do_first = ctx->retry_policy != TDA_RETRY_ONLY, do_ladder = ctx->retry_policy != TDA_RETRY_FIRST_PASS;
@@ -1837,14 +1839,14 @@ tda_status launch_rips_dm(tda_ctx* ctx, const double* dm, int n_win, int n, doub
     return order_h1(ctx, h1, h1_cap, h1_cnt, n_win, st);
 }
 
-template <int NB, bool RES, int W, bool RETRY>
+template <int NB, bool RES, int W, bool RETRY, typename WT = u64>
 static tda_status launch_eeg_t(tda_ctx* ctx, const WindowSource& win, int n_win, int n_ch, int n_t, float thresh, RipsOut out,
                                double* dist, double* corr, hipStream_t st)
 {
-    RipsLayout L = make_layout(n_ch, W * 8, n_ch * (n_ch - 1) / 2 * 4, 256);
+    RipsLayout L = make_layout(n_ch, W * (int)sizeof(WT), n_ch * (n_ch - 1) / 2 * 4, 256);
     if ((size_t)L.total < CdLayout<NB>::BYTES) L.total = (int)((CdLayout<NB>::BYTES + 15) & ~(size_t)15);
     if (L.total > LDS_MAX) TDA_FAIL(ctx, TDA_ERR_UNSUPPORTED, "window too large for LDS");
-    auto kern = eeg_window_kernel<NB, RES, W, RETRY>;
+    auto kern = eeg_window_kernel<NB, RES, W, RETRY, WT>;
     if (L.total > 48 * 1024)
         TDA_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, L.total));
@@ -1864,16 +1866,23 @@ static tda_status launch_eeg_ladder(tda_ctx* ctx, const WindowSource& win, int n
                                     double* dist, double* corr, hipStream_t st)
 {
     const bool do_first = ctx->retry_policy != TDA_RETRY_ONLY, do_ladder = ctx->retry_policy != TDA_RETRY_FIRST_PASS;
+    const bool one_step = ctx->retry_policy == TDA_RETRY_ONE_STEP;
     tda_status rc = TDA_OK;
-    const int W = ctx->words_dm >= 2 ? 2 : 1;
-    if (do_first)
-        rc = W == 1 ? launch_eeg_t<3, RES, 1, false>(ctx, win, n_win, n_ch, n_t, th, out, dist, corr, st)
-                    : launch_eeg_t<3, RES, 2, false>(ctx, win, n_win, n_ch, n_t, th, out, dist, corr, st);
-    // widening passes recompute the flagged windows from the samples (the matrix was never stored): 128 bits, then
-    // 512, which covers the theoretical maximum of 506 classes alive at once for 47 points
-    if (do_ladder && rc == TDA_OK && W == 1)
+    // ladder of the fused kernel: 32 (words_dm = 0) -> 64 -> 128 -> 512 class bits; every wider pass recomputes the
+    // flagged windows from the samples (the matrix was never stored); 512 covers the theoretical maximum of 506
+    // classes alive at once for 47 points
+    const int first = ctx->words_dm >= 2 ? 2 : ctx->words_dm;       // 0, 1 or 2
+    if (do_first) {
+        if (first == 0) rc = launch_eeg_t<3, RES, 1, false, u32>(ctx, win, n_win, n_ch, n_t, th, out, dist, corr, st);
+        else if (first == 1) rc = launch_eeg_t<3, RES, 1, false>(ctx, win, n_win, n_ch, n_t, th, out, dist, corr, st);
+        else rc = launch_eeg_t<3, RES, 2, false>(ctx, win, n_win, n_ch, n_t, th, out, dist, corr, st);
+    }
+    int rung = 0;
+    if (do_ladder && rc == TDA_OK && first == 0 && !(one_step && rung++ >= 1))
+        rc = launch_eeg_t<3, RES, 1, true>(ctx, win, n_win, n_ch, n_t, th, out, dist, corr, st);
+    if (do_ladder && rc == TDA_OK && first <= 1 && !(one_step && rung++ >= 1))
         rc = launch_eeg_t<3, RES, 2, true>(ctx, win, n_win, n_ch, n_t, th, out, dist, corr, st);
-    if (do_ladder && rc == TDA_OK && !(ctx->retry_policy == TDA_RETRY_ONE_STEP && W == 1))
+    if (do_ladder && rc == TDA_OK && !(one_step && rung++ >= 1))
         rc = launch_eeg_t<3, RES, 8, true>(ctx, win, n_win, n_ch, n_t, th, out, dist, corr, st);
     return rc;
 }

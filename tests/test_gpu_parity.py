@@ -561,7 +561,7 @@ def test_fused_eeg_window_equals_two_kernels(ctx):
     corr = torch.empty_like(dist)
     engine.corr_dist_dev(wt, dist, corr, ctx=ctx)
     two = engine.rips_dm_dev(dist, ctx=ctx)
-    for words in (1, 2):
+    for words in (0, 1, 2):              # 32 (fused kernel only), 64, 128 class bits in the first pass
         ctx.set_class_words(words, 1)
         try:
             d2 = torch.full_like(dist, -1.0)
@@ -596,23 +596,25 @@ def test_fused_eeg_window_widening_passes(ctx):
     wt = torch.from_numpy(W).to(dev)
     dist = engine.corr_dist_dev(wt, ctx=ctx)
     two = engine.rips_dm_dev(dist, ctx=ctx)
-    ctx.set_class_words(1, 1)
-    try:
-        ctx.set_retry_policy(ctx.RETRY_FIRST_PASS)
-        first = engine.eeg_window_dev(wt, ctx=ctx)
+    b0, b1 = two.to_lists()
+    for words in (1, 0):                 # ladders 64 -> 128 -> 512 and 32 -> 64 -> 128 -> 512
+        ctx.set_class_words(words, 1)
+        try:
+            ctx.set_retry_policy(ctx.RETRY_FIRST_PASS)
+            first = engine.eeg_window_dev(wt, ctx=ctx)
+            torch.cuda.synchronize()
+            flagged = int((first.status & 2).ne(0).sum())
+            ctx.set_retry_policy(ctx.RETRY_AUTO)
+            one = engine.eeg_window_dev(wt, ctx=ctx)
+        finally:
+            ctx.set_retry_policy(ctx.RETRY_AUTO)
+            ctx.set_class_words(2, 1)
         torch.cuda.synchronize()
-        flagged = int((first.status & 2).ne(0).sum())
-        ctx.set_retry_policy(ctx.RETRY_AUTO)
-        one = engine.eeg_window_dev(wt, ctx=ctx)
-    finally:
-        ctx.set_retry_policy(ctx.RETRY_AUTO)
-        ctx.set_class_words(2, 1)
-    torch.cuda.synchronize()
-    assert flagged > 0, "the test needs windows that overflow 64 class bits"
-    assert int(one.status.max()) == 0 and torch.equal(one.c0, two.c0) and torch.equal(one.c1, two.c1)
-    a0, a1 = one.to_lists(); b0, b1 = two.to_lists()
-    for w in range(96):
-        assert np.array_equal(a0[w], b0[w]) and np.array_equal(a1[w], b1[w])
+        assert flagged > 0, "the test needs windows that overflow the first pass"
+        assert int(one.status.max()) == 0 and torch.equal(one.c0, two.c0) and torch.equal(one.c1, two.c1)
+        a0, a1 = one.to_lists()
+        for w in range(96):
+            assert np.array_equal(a0[w], b0[w]) and np.array_equal(a1[w], b1[w])
 
 
 def _bipartite_windows(n_rep, seed):

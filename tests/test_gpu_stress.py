@@ -32,7 +32,7 @@ def test_stress_audio_windows_all_bands(stress, ctx, words):
         ctx.set_class_words(2, 1)
 
 
-@pytest.mark.parametrize("words", [(2, 1), (1, 1)])
+@pytest.mark.parametrize("words", [(2, 1), (1, 1), (0, 1)])
 def test_stress_matrices_thresholds_and_fused_kernel(stress, ctx, words):
     ctx.set_class_words(*words)
     try:
