@@ -734,3 +734,40 @@ def test_ranking_degenerate_key_distributions(ctx):
         o = port.rips_dm(W[w])
         assert st[w] == 0 and _same_multiset(h0[w], o[0]) and _same_multiset(h1[w], o[1])
     assert len(h0[1]) >= 1
+
+
+def test_corpus_pass_rows_vs_oracle(ctx):
+    """pipeline.CorpusPass -- the loops of run_analysis / process_recording turned inside out (cmp:131-138, 63-122): a
+    small corpus (7 recordings x 5 bands x 15 windows, bench.py's generators) through band batches, lanes, HIP graphs
+    and the per-pass row block, against the CPU restatement of every (recording, band) group; two passes give
+    identical rows, and the widening passes leave no status word set."""
+    import torch
+    from oracle import port
+    from tda_eeg_audio_amd import pipeline
+    dev = torch.device("cuda", ctx.device)
+    n_rec, wpr, bands = 7, 15, synth.BANDS
+    recs = np.arange(n_rec)
+    eeg = synth.corpus_eeg_dev(recs, wpr, len(bands), dev, seed=9)
+    aud_all = synth.corpus_audio(n_rec, wpr, bands, seed=11)
+    aud = [torch.from_numpy(np.ascontiguousarray(aud_all[b].reshape(-1, 250))).to(dev) for b in bands]
+    ctx.set_class_words(1, 1)
+    try:
+        runner = pipeline.CorpusPass(eeg, aud, wpr, dev, ctx, depth=3, graph=True)
+        runner.step()
+        first = runner.finish().clone()
+        runner.step(); runner.step()
+        rows = runner.finish()
+        torch.cuda.synchronize()
+    finally:
+        ctx.set_class_words(2, 1)
+    assert rows.shape == (n_rec, len(bands) * 48) and torch.equal(rows, first)
+    for ws in runner.lanes.ws:
+        assert int(ws.eeg.status.max()) == 0 and int((ws.aud.status & ~4).max()) == 0
+    got = rows.cpu().numpy().reshape(n_rec, len(bands), 48)
+    for bi, b in enumerate(bands):
+        e = eeg[bi].cpu().numpy(); a = aud[bi].cpu().numpy()
+        for r in range(n_rec):
+            ref = port.segment_step(e[r * wpr:(r + 1) * wpr], a[r * wpr:(r + 1) * wpr])
+            assert np.abs(got[r, bi, :2] - ref[:2]).max() < 1e-6, (b, r)           # Wasserstein means (north_star bar)
+            assert np.array_equal(got[r, bi, 2:4], ref[2:4])                        # tau, window count
+            assert np.allclose(got[r, bi, 4:], ref[4:], rtol=1e-9, atol=1e-12)
