@@ -771,3 +771,45 @@ def test_corpus_pass_rows_vs_oracle(ctx):
             assert np.abs(got[r, bi, :2] - ref[:2]).max() < 1e-6, (b, r)           # Wasserstein means (north_star bar)
             assert np.array_equal(got[r, bi, 2:4], ref[2:4])                        # tau, window count
             assert np.allclose(got[r, bi, 4:], ref[4:], rtol=1e-9, atol=1e-12)
+
+
+def test_api_edge_cases_empty_truncated_oversized_and_bad_arguments(ctx):
+    """The error conventions of SURVEY.md section 8b at the C ABI: empty batches are no-ops, more H1 rows than h1_cap
+    is reported per window with the TRUE count (status bit 1) and the rows that fit, a tau that would give more than
+    TDA_MAX_POINTS points (or tau < 1) is flagged (bit 16) without touching the other windows, < 3 points gives
+    [[0,0]],[[0,0]] (bit 4, utils.py:125-126), and bad arguments come back as error codes with a message, never a
+    crash."""
+    from tda_eeg_audio_amd import _lib
+    # empty batches
+    h0, h1, st = engine.rips_dm_batch(np.zeros((0, 47, 47)), ctx=ctx)
+    assert h0 == [] and h1 == [] and len(st) == 0
+    assert engine.corr_dist_batch(np.zeros((0, 47, 250)), want_corr=False, ctx=ctx).shape == (0, 47, 47)
+    assert engine.tau_batch(np.zeros((0, 250)), 125, ctx=ctx).shape == (0,)
+    assert engine.wasserstein_batch(*engine.pack_diagrams([]), *engine.pack_diagrams([]), ctx=ctx).shape == (0,)
+    # H1 capacity: true count reported, first rows kept
+    W = synth.eeg_windows(4, seed=8, kind="white")
+    dist = engine.corr_dist_batch(W, want_corr=False, ctx=ctx)
+    full0, full1, st_full = engine.rips_dm_batch(dist, h1_cap=1024, ctx=ctx)
+    a0, c0, a1, c1, st = engine.rips_dm_batch(dist, h1_cap=8, ctx=ctx, raw=True)
+    assert (st_full == 0).all() and (st & 1).all() and not (st & 2).any()
+    assert np.array_equal(c1, [len(d) for d in full1]) and all(len(d) > 8 for d in full1)
+    assert all(_same_multiset(x, y) for x, y in zip([a0[i, :c0[i]] for i in range(4)], full0))
+    # clouds: tau = 0 (more points than the kernel takes / not a delay), tau = 124 (one point), ordinary
+    aw = synth.audio_windows(3, "alpha", seed=2)
+    h0, h1, npts, st = engine.takens_rips_batch(aw, np.array([0, 124, 7], np.int32), ctx=ctx)
+    assert st[0] & 16 and len(h0[0]) == 0 and len(h1[0]) == 0
+    assert st[1] == 4 and npts[1] == 1 and np.array_equal(h0[1], [[0.0, 0.0]]) and np.array_equal(h1[1], [[0.0, 0.0]])
+    o = port.audio_persistence(aw[2], 7)[0]
+    assert st[2] == 0 and _same_multiset(h0[2], o[0]) and _same_multiset(h1[2], o[1])
+    # bad arguments: error code + message, the context stays usable
+    with pytest.raises(_lib.TdaError, match="n must be in"):
+        engine.rips_dm_batch(np.zeros((1, 200, 200)), ctx=ctx)
+    with pytest.raises(_lib.TdaError, match="class words"):
+        ctx.set_class_words(3, 1)
+    with pytest.raises(_lib.TdaError, match="33..48 channels"):
+        import torch
+        engine.eeg_window_dev(torch.zeros((2, 20, 250), dtype=torch.float64, device=torch.device("cuda", ctx.device)), ctx=ctx)
+    with pytest.raises(ValueError, match="Unknown method"):
+        engine.corr_to_dist_batch(np.zeros((1, 4, 4)), method="cosine", ctx=ctx)
+    h0, h1, st = engine.rips_dm_batch(dist[:1], ctx=ctx)
+    assert st[0] == 0
