@@ -62,17 +62,24 @@ def parse_args():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the features / PCIe legs")
     ap.add_argument("--no-graph", action="store_true", help="launch every step eagerly instead of replaying HIP graphs")
-    ap.add_argument("--lanes", type=int, default=int(os.environ.get("TDA_LANES", "5")),
-                    help="band batches in flight (pipeline.Lanes): one lane per band (the corpus workload is insensitive "
-                         "to it, 2-5 lanes within 1 %%; the 710-window batches of configs[1] gain 14 %% over three lanes)")
+    ap.add_argument("--lanes", type=int, default=int(os.environ.get("TDA_LANES", "0")),
+                    help="batches in flight (pipeline.Lanes); 0 = 3 with one batch per pass (2-5 lanes lie within 1 %% on "
+                         "the full corpus, 3 is best on an eighth of it), 5 with --per-band or --workload batch710 (one "
+                         "lane per band: the 710-window batches of configs[1] gain 14 %% over three lanes)")
     ap.add_argument("--class-words", default=os.environ.get("TDA_CLASS_WORDS", "1,1"),
                     help="first-pass class capacity (x64 bits for EEG, x32/x64 for audio); windows that need more are "
                          "redone by the widening passes inside the same step and counted in windows_repaired")
+    ap.add_argument("--per-band", action="store_true", default=os.environ.get("TDA_PER_BAND", "0") == "1",
+                    help="one batch per band and pass (five launches per stage) instead of all bands of the rank's share "
+                         "in one batch")
     ap.add_argument("--share-gpu", action="store_true",
                     help="rehearsal only: every rank uses cuda:0 and the all-gather goes through gloo "
                          "(exercises the N>1 code path on a one-GPU box; numbers are meaningless)")
     ap.add_argument("--cpu-worker", default=None, help=argparse.SUPPRESS)     # internal: the cpu_baseline child process
-    return ap.parse_args()
+    args = ap.parse_args()
+    if args.lanes <= 0:
+        args.lanes = 5 if (args.per_band or args.workload == "batch710") else 3
+    return args
 
 
 # ------------------------------------------------------------------------------------------------------------
@@ -165,7 +172,7 @@ def main():
         aud_all = synth.corpus_audio(n_rec, wpr, bands, seed=4242)
         aud = [torch.from_numpy(np.ascontiguousarray(aud_all[b][mine].reshape(-1, 250))).to(device) for b in bands]
         runner = pipeline.CorpusPass(eeg, aud, wpr, device, ctx, depth=args.lanes, graph=not args.no_graph,
-                                     my_recs=mine, shards=shards, n_total=n_rec)
+                                     my_recs=mine, shards=shards, n_total=n_rec, merge_bands=not args.per_band)
     else:                                         # batch710: ragged last recording -> explicit group offsets
         assert world == 1, "--workload batch710 is the one-GPU configuration"
         seg_off = np.concatenate([[0], np.cumsum(counts)]).astype(np.int32)
@@ -180,7 +187,8 @@ def main():
                                      seg_off=seg_off)
     torch.cuda.synchronize()
     t_gen = time.perf_counter() - t_gen
-    n_win_batch = runner.n_win                    # windows per band-batch on this rank
+    n_win_batch = runner.n_win                    # windows per batch (= per launch of every stage) on this rank
+    n_batches = len(runner.batches)
     total_pairs = int(counts.sum()) * nb          # window pairs of one pass of the whole job
     lanes = runner.lanes
 
@@ -199,12 +207,12 @@ def main():
 
     # ---- warm-up: one eager pass with per-stage events (stage_ms, event_ms), then W passes (the first captures) ----
     ev_log, probes = [], []
-    for b in range(nb):
+    for b, (eb, ab, _) in enumerate(runner.batches):
         timers = {s: (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
                   for s in pipeline.STAGES}
         cur_events[0] = (ctx.new_event(), ctx.new_event())
         probes.append(cur_events[0])
-        lanes.submit(eeg[b], aud[b], ctx=ctx, timers=timers, sync_inputs=False, lane=b)
+        lanes.submit(eb, ab, ctx=ctx, timers=timers, sync_inputs=False, lane=b)
         lanes.drain()
         ev_log.append(timers)
     cur_events[0] = None
@@ -218,6 +226,7 @@ def main():
     stage_ms = {s: v for s, v in stage_ms.items() if v > 0.0}
     event_ms = [ctx.elapsed_ms(a, b) for a, b in probes]
     try:
+        runner.prime()                          # every lane captures its graph (set-up, not a warm-up step)
         for _ in range(max(1, args.warmup)):
             runner.step()
         rows = runner.finish()
@@ -277,7 +286,7 @@ def main():
     if rank == 0:
         value = total_pairs * args.steps / dt
         launches = int(sp[:, 3].sum() - sp_before[:, 3].sum())
-        exp = args.steps * nb
+        exp = args.steps * n_batches
         assert launches == exp, f"probe saw {launches} launches of the dominant kernel, expected {exp}"
         kernel_ms = float(sp[:, 2].sum() - sp_before[:, 2].sum()) / launches / 100e6 * 1e3   # timed region only
         kernel_ms_all = float(sp[:, 2].sum()) / int(sp[:, 3].sum()) / 100e6 * 1e3            # every launch of the process
@@ -305,9 +314,9 @@ def main():
                                    f"recording-band, Takens dim 3 sub 2 + Rips (audio, 23..123 pts over the bands), "
                                    f"Wasserstein H0+H1, features, per-recording reductions; one all-gather of the "
                                    f"({n_rec}, {nb}x48) rows per pass",
-                       "windows_per_pass": total_pairs, "windows_per_gpu_per_pass": int(n_win_batch * nb),
+                       "windows_per_pass": total_pairs, "windows_per_gpu_per_pass": int(n_win_batch * n_batches),
                        "input_bytes_per_gpu": int(sum(e.numel() for e in eeg) * 8 + sum(a.numel() for a in aud) * 8),
-                       "band_batches_per_pass": nb, "windows_per_band_batch": int(n_win_batch), "thresh": 2.0,
+                       "batches_per_pass": n_batches, "windows_per_batch": int(n_win_batch), "thresh": 2.0,
                        "parallelism": f"recordings dealt over {world} rank(s), one all-gather per pass",
                        "batches_in_flight": lanes.depth, "hip_graph": lanes.graph,
                        "first_pass_class_bits": {"eeg": 64 * cw_dm, "audio": 32 * cw_cloud if cw_cloud == 1 else 64},
@@ -322,7 +331,7 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "rips_cloud_kernel<512, 1, unsigned int> (stage rips_audio)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel_ms": round(kernel_ms, 4),
-                         "event_ms": round(float(np.mean(event_ms)), 4), "event_ms_per_band": [round(x, 4) for x in event_ms],
+                         "event_ms": round(float(np.mean(event_ms)), 4), "event_ms_per_batch": [round(x, 4) for x in event_ms],
                          "kernel_ms_all_launches": round(kernel_ms_all, 4),
                          "launches_probed": int(sp[:, 3].sum()),
                          "alg_bytes_per_launch": ALG_BYTES[DOM] * n_win_batch,

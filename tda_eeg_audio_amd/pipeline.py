@@ -254,16 +254,37 @@ class CorpusPass:
     scripts/tda_eeg_classification_v2.py:608-638."""
 
     def __init__(self, eeg, aud, wpr, device, ctx, depth=3, graph=True, my_recs=None, shards=None, n_total=None,
-                 gather=True, seg_off=None, **lane_kw):
+                 gather=True, seg_off=None, merge_bands=False, **lane_kw):
+        """merge_bands: all bands of the rank's share as ONE batch per pass (band-major groups) instead of one batch
+        per band -- five times the windows per launch, which matters when the share is small (a rank of eight holds
+        2,655 windows per band: 5.2 rounds of the audio kernel)."""
         import torch
-        self.eeg, self.aud, self.ctx = eeg, aud, ctx
+        self.ctx = ctx
         self.n_bands = len(eeg)
         n_win = eeg[0].shape[0]
         assert all(e.shape[0] == n_win for e in eeg) and all(a.shape[0] == n_win for a in aud)
         if seg_off is None:                       # wpr selected windows per recording-band
             assert n_win % wpr == 0
             seg_off = np.arange(0, n_win + 1, wpr, dtype=np.int32)
-        self.n_rec, self.n_win = len(seg_off) - 1, n_win
+        seg_off = np.asarray(seg_off, np.int32)
+        self.n_rec = len(seg_off) - 1
+        if merge_bands and self.n_bands > 1:
+            base = getattr(eeg[0], "_base", None)
+            step_b = eeg[0].numel() * eeg[0].element_size()
+            if base is not None and base.is_contiguous() and all(e.is_contiguous() and e.data_ptr() == eeg[0].data_ptr() + b * step_b
+                                                                   for b, e in enumerate(eeg)) \
+                    and base.numel() == self.n_bands * eeg[0].numel() and base.data_ptr() == eeg[0].data_ptr():
+                eeg_all = base.view(self.n_bands * n_win, *eeg[0].shape[1:])          # the bands already lie back to back
+            else:
+                eeg_all = torch.cat(list(eeg))
+            aud_all = torch.cat(list(aud))
+            seg_all = np.concatenate([[0]] + [seg_off[1:] + b * n_win for b in range(self.n_bands)]).astype(np.int32)
+            self.batches = [(eeg_all, aud_all, list(range(self.n_bands)))]
+            seg_off, n_win = seg_all, self.n_bands * n_win
+        else:
+            self.batches = [(eeg[b], aud[b], [b]) for b in range(self.n_bands)]
+        self.eeg, self.aud = [b[0] for b in self.batches], [b[1] for b in self.batches]
+        self.n_win = n_win                        # windows per batch (= per launch of every stage)
         # big batches: ONE widening pass rides along with every Rips call (a few windows in ten thousand need it, and
         # it fits beside the other kernels); the wide rungs of the ladder, which would wait for a nearly empty CU
         # even with nothing to redo, run only for a batch whose flags are still set when it is verified
@@ -277,13 +298,17 @@ class CorpusPass:
         self.gathered = None
         self._open = {}
 
-    def _post(self, k, b, result):
-        """Runs on the lane's stream when band b of pass k has been verified: its rows join the pass' block; the
-        last band to arrive (any order) all-gathers the block."""
+    def _post(self, k, i, result):
+        """Runs on the lane's stream when batch i of pass k has been verified: its rows join the pass' block; the
+        last batch to arrive (any order) all-gathers the block."""
         import torch
         blk = self.blocks[k % len(self.blocks)]
-        blk[:, b].copy_(result)
-        st = self._open.setdefault(k, {"left": self.n_bands, "events": []})
+        bands = self.batches[i][2]
+        if len(bands) == 1:
+            blk[:, bands[0]].copy_(result)
+        else:                                     # groups are band-major: (band, recording) -> (recording, band)
+            blk.copy_(result.view(len(bands), self.n_rec, RESULT_COLS).transpose(0, 1))
+        st = self._open.setdefault(k, {"left": len(self.batches), "events": []})
         ev = torch.cuda.Event()
         ev.record()
         st["events"].append(ev)
@@ -298,18 +323,27 @@ class CorpusPass:
                 from . import dist as tdist
                 self.gathered = tdist.all_gather_rows(flat, self.my_recs, self.shards, self.n_total)
             else:
-                self.gathered = flat
+                self.gathered = flat.clone() if len(self.batches) == 1 else flat
         return None
 
     def step(self, timers=None):
-        """Enqueue one pass (one batch per band).  timers: optional {band index: stage-event dict} -- those bands
-        are launched eagerly with per-stage events (see run_step)."""
+        """Enqueue one pass (one batch per band, or one in all).  timers: optional {batch index: stage-event dict} --
+        those batches are launched eagerly with per-stage events (see run_step)."""
         import functools
         k = self.passes
         self.passes += 1
-        for b in range(self.n_bands):
-            self.lanes.submit(self.eeg[b], self.aud[b], ctx=self.ctx, post=functools.partial(self._post, k, b),
-                              sync_inputs=False, lane=b, timers=(timers or {}).get(b))
+        for i, (e, a, _) in enumerate(self.batches):
+            # one batch per pass: passes alternate over the lanes; otherwise batch i always on lane i mod depth
+            lane = (k if len(self.batches) == 1 else i)
+            self.lanes.submit(e, a, ctx=self.ctx, post=functools.partial(self._post, k, i), sync_inputs=False,
+                              lane=lane, timers=(timers or {}).get(i))
+
+    def prime(self):
+        """Untimed set-up: every lane launches its step once eagerly and captures it, so that no later pass pays for
+        a capture (with one batch per pass the lanes take turns, and the first `depth` passes would each capture)."""
+        for _ in range(self.lanes.depth if len(self.batches) == 1 else 1):
+            self.step()
+        return self.finish()
 
     def finish(self):
         """Verify and publish everything in flight; returns the rows of the last pass:

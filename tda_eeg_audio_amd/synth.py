@@ -93,7 +93,8 @@ def corpus_eeg_dev(rec_ids, n_per_rec, n_bands, device, seed=42, n_ch=N_CH, n_t=
     the random-number plumbing here; nothing of the hot path runs in it."""
     import torch
     f64 = dict(dtype=torch.float64, device=device)
-    out = [torch.empty((len(rec_ids) * n_per_rec, n_ch, n_t), **f64) for _ in range(n_bands)]
+    base = torch.empty((n_bands, len(rec_ids) * n_per_rec, n_ch, n_t), **f64)      # the bands lie back to back
+    out = [base[b] for b in range(n_bands)]
     g = torch.Generator(device=device)
     for i, rec in enumerate(rec_ids):
         g.manual_seed(int(seed) * 1000003 + int(rec))

@@ -736,11 +736,13 @@ def test_ranking_degenerate_key_distributions(ctx):
     assert len(h0[1]) >= 1
 
 
-def test_corpus_pass_rows_vs_oracle(ctx):
+@pytest.mark.parametrize("merge", [False, True], ids=["per_band", "merged"])
+def test_corpus_pass_rows_vs_oracle(ctx, merge):
     """pipeline.CorpusPass -- the loops of run_analysis / process_recording turned inside out (cmp:131-138, 63-122): a
     small corpus (7 recordings x 5 bands x 15 windows, bench.py's generators) through band batches, lanes, HIP graphs
     and the per-pass row block, against the CPU restatement of every (recording, band) group; two passes give
-    identical rows, and the widening passes leave no status word set."""
+    identical rows, and the widening passes leave no status word set.  merged: all five bands as ONE batch per pass
+    (band-major groups; the EEG bands are views of one allocation, the audio bands are concatenated)."""
     import torch
     from oracle import port
     from tda_eeg_audio_amd import pipeline
@@ -752,12 +754,19 @@ def test_corpus_pass_rows_vs_oracle(ctx):
     aud = [torch.from_numpy(np.ascontiguousarray(aud_all[b].reshape(-1, 250))).to(dev) for b in bands]
     ctx.set_class_words(1, 1)
     try:
-        runner = pipeline.CorpusPass(eeg, aud, wpr, dev, ctx, depth=3, graph=True)
+        runner = pipeline.CorpusPass(eeg, aud, wpr, dev, ctx, depth=3, graph=True, merge_bands=merge)
+        assert len(runner.batches) == (1 if merge else len(bands))
         runner.step()
         first = runner.finish().clone()
         runner.step(); runner.step()
         rows = runner.finish()
         torch.cuda.synchronize()
+        if merge:                                  # bands that are separate allocations are concatenated: same rows
+            again = pipeline.CorpusPass([e.clone() for e in eeg], aud, wpr, dev, ctx, depth=2, graph=False,
+                                        merge_bands=True)
+            assert again.eeg[0].data_ptr() != eeg[0].data_ptr() and runner.eeg[0].data_ptr() == eeg[0].data_ptr()
+            again.step()
+            assert torch.equal(again.finish(), rows)
     finally:
         ctx.set_class_words(2, 1)
     assert rows.shape == (n_rec, len(bands) * 48) and torch.equal(rows, first)
