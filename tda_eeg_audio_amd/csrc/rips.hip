@@ -377,6 +377,14 @@ struct RipsLayout {
 // layout, written when the ranking phase is over (it legitimately uses the space across the regions) and checked
 // after the sweep; an overwritten sentinel sets status bit TDA_WIN_LDS_GUARD.  The product build has no gaps.
 #define TDA_WIN_LDS_GUARD 0x100
+// One wave works while the others of its workgroup wait at a barrier: it goes first at its SIMD's issue port
+// (the other workgroups' waves there lose nothing in total, the waiting seven get going sooner).
+#ifndef TDA_SOLO_PRIO
+#define TDA_SOLO_PRIO 3
+#endif
+#define TDA_SOLO_BEGIN() __builtin_amdgcn_s_setprio(TDA_SOLO_PRIO)
+#define TDA_SOLO_END() __builtin_amdgcn_s_setprio(0)
+
 #ifdef TDA_DEBUG_PTS
 #define GUARD_BYTES 16
 __device__ __forceinline__ void guard_write(unsigned char* smem, const RipsLayout& L)
@@ -573,6 +581,7 @@ __device__ void rips_sweep(int n, int E, int Ev, const u16* rank, const u16* ord
                     // the vote above and the barrier below; this round's bbest is still being read by the others, so
                     // it is left alone and the OTHER set (last read a round ago) is wiped for the next round.
                     if (wave == 0) {
+                        TDA_SOLO_BEGIN();
                         int pp[2];
 #pragma unroll
                         for (int h = 0; h < 2; ++h) {
@@ -599,6 +608,7 @@ __device__ void rips_sweep(int n, int E, int Ev, const u16* rank, const u16* ord
                         bcomp[lane] = n0; bcomp[64 + lane] = n1;
                         u32* other = bbest2 + 128 * ((round + 1) & 1);
                         other[lane] = 0xffffffffu; other[64 + lane] = 0xffffffffu;
+                        TDA_SOLO_END();
                     }
                     __syncthreads();
                 }
@@ -628,6 +638,7 @@ __device__ void rips_sweep(int n, int E, int Ev, const u16* rank, const u16* ord
             if (wave == 0) { compA = bcomp[lane]; compB = bcomp[64 + lane]; }
         }
         if (wave == 0) {
+            TDA_SOLO_BEGIN();
             // The walk stops at the first birth that finds no free class bit: the chunk is closed just before
             // that edge, so that the kills of the shortened chunk can free bits (capacity = classes alive at
             // once).  q = NT: the whole chunk went through.
@@ -686,6 +697,7 @@ __device__ void rips_sweep(int n, int E, int Ev, const u16* rank, const u16* ord
             }
             if (lane < NT / 64) { offs[lane] = pb; offs[8 + lane] = pr; }
             if (lane == 0) { offs[16] = tb; offs[17] = tr; offs[18] = tm; offs[19] = q; }
+            TDA_SOLO_END();
         } else {
             // meanwhile: the j-th free class index (every class looks up its own rank among the free ones)
             for (int t = tid - 64; t < WB * W; t += NT - 64) {
@@ -897,12 +909,21 @@ __device__ void rips_sweep(int n, int E, int Ev, const u16* rank, const u16* ord
         // the chunk is listed again.
         const int ta_ = tri2(a), tb_ = tri2(b);
         constexpr int ES = 4 + W * (int)sizeof(WT);                  // list entry: key, vector
-        constexpr int LCAP = (MISC_LIST_BYTES / ES) < 256 ? (MISC_LIST_BYTES / ES) : 256;
+        // One class word: wave 0 puts the list into the order of the killing edges first (counting sort on the lane
+        // that listed the entry: every thread leaves its number of entries in hist[], entry keys carry their index
+        // within the thread in bits 24..31), so that "the earliest non-zero vector" is a ballot and a count of
+        // trailing zeros instead of a reduction over the wave.  Entries of ONE edge may come in any order: the
+        // classes they kill and the images of those classes depend on their span only.
+        constexpr bool SORTED = W == 1;
+        constexpr int HIST_BYTES = SORTED ? NT + 8 : 0;              // u8 hist[NT] behind the entries (8-byte aligned)
+        constexpr int LMAX = SORTED ? 255 : 256;                     // (sorted: offsets are bytes)
+        constexpr int LCAP = ((MISC_LIST_BYTES - HIST_BYTES) / ES) < LMAX ? ((MISC_LIST_BYTES - HIST_BYTES) / ES) : LMAX;
         constexpr int LPL = (LCAP + 63) / 64;
         // class-indexed image table (one Psi per class) when it fits the list area; else kill records
         constexpr bool FTAB = WB * W * (int)sizeof(Psi<W, WT>) <= MISC_LIST_BYTES;
         constexpr int KMAX = FTAB ? 64 : LCAP;                       // kills per reduction round
         unsigned char* list = misc + MISC_LIST;
+        unsigned char* hist = list + ((LCAP * ES + 7) & ~7);
         const u32 mws[4] = {m0, m1, m2, m3};
 #ifdef TDA_PROFILE
         {   // diagnostic: triangles left to test after the link closure, and apparent edges
@@ -920,6 +941,7 @@ __device__ void rips_sweep(int n, int E, int Ev, const u16* rank, const u16* ord
             }
             u32 firstkey = 0xffffffffu;
             Psi<W, WT> firsty = pzero<W, WT>();
+            u32 mycnt = 0u;                                          // entries of this thread in this round
             if (apparent) {
                 base = psi[tab];
                 Psi<W, WT> prev = pzero<W, WT>();                    // a repeated vector reduces to zero: skip it
@@ -953,15 +975,17 @@ __device__ void rips_sweep(int n, int E, int Ev, const u16* rank, const u16* ord
                             if (firstkey == 0xffffffffu) { firstkey = key; firsty = ys[k]; }
                             const u32 idx = atomicAdd(&lcnt[0], 1u);
                             if (idx < (u32)LCAP) {
-                                *reinterpret_cast<u32*>(list + ES * idx) = key;
+                                *reinterpret_cast<u32*>(list + ES * idx) = SORTED ? key | (mycnt << 24) : key;
 #pragma unroll
                                 for (int c = 0; c < W; ++c)
                                     *reinterpret_cast<WT*>(list + ES * idx + 4 + c * (int)sizeof(WT)) = ys[k].w[c];
                             }
+                            ++mycnt;
                         }
                     }
                 }
             }
+            if (SORTED) hist[tid] = (unsigned char)mycnt;
             {
                 const u32 wmin = wave_min_u32_dpp(firstkey);
                 if (lane == 0 && wmin != 0xffffffffu) atomicMin(&lcnt[1], wmin);
@@ -987,6 +1011,7 @@ __device__ void rips_sweep(int n, int E, int Ev, const u16* rank, const u16* ord
 #pragma unroll
             for (int c = 0; c < W; ++c) alive_before[c] = alive[c];
             if (wave == 0) {
+                TDA_SOLO_BEGIN();
                 const int nl = complete ? (int)cnt : 1;
                 u32 ek[LPL];
                 Psi<W, WT> ev[LPL];
@@ -999,6 +1024,34 @@ __device__ void rips_sweep(int n, int E, int Ev, const u16* rank, const u16* ord
 #pragma unroll
                         for (int c = 0; c < W; ++c)
                             ev[q].w[c] = *reinterpret_cast<const WT*>(list + ES * idx + 4 + c * (int)sizeof(WT));
+                    }
+                }
+                if (SORTED && complete) {
+                    // exclusive prefix over hist[] (HW packed words of four counts per lane; at most 255 entries, so
+                    // bytes never carry), entries written back at offset-of-thread + index-in-thread, reloaded
+                    constexpr int HW = NT / 256;
+                    u32* hw = reinterpret_cast<u32*>(hist) + HW * lane;
+                    const u32 x0 = hw[0], x1 = HW == 2 ? hw[HW - 1] : 0u;
+                    const u32 s0 = __builtin_amdgcn_sad_u8(x0, 0u, 0u);
+                    const u32 tot = HW == 2 ? __builtin_amdgcn_sad_u8(x1, 0u, s0) : s0;
+                    const u32 before = (u32)wave_incl_scan_i32((int)tot) - tot;
+                    hw[0] = x0 * 0x01010101u - x0 + before * 0x01010101u;
+                    if (HW == 2) hw[HW - 1] = x1 * 0x01010101u - x1 + (before + s0) * 0x01010101u;
+#pragma unroll
+                    for (int q = 0; q < LPL; ++q) {
+                        if (lane + 64 * q < nl) {
+                            const int pos = (int)hist[(ek[q] >> 8) & 0xffffu] + (int)(ek[q] >> 24);
+                            *reinterpret_cast<u32*>(list + ES * pos) = ek[q] & 0x00ffffffu;
+                            *reinterpret_cast<WT*>(list + ES * pos + 4) = ev[q].w[0];
+                        }
+                    }
+#pragma unroll
+                    for (int q = 0; q < LPL; ++q) {
+                        const int idx = lane + 64 * q;
+                        if (idx < nl) {
+                            ek[q] = *reinterpret_cast<const u32*>(list + ES * idx);
+                            ev[q].w[0] = *reinterpret_cast<const WT*>(list + ES * idx + 4);
+                        }
                     }
                 }
                 // birth rank / length of the classes: lane i keeps bit i of every word
@@ -1019,6 +1072,64 @@ __device__ void rips_sweep(int n, int E, int Ev, const u16* rank, const u16* ord
                 int nk = 0, more = 0;
                 const int nq = (nl + 63) >> 6;                        // register blocks the list reaches (wave-uniform)
                 PROF_MARK(30);
+                if constexpr (SORTED) {
+                    // Block by block in list order.  Lane j keeps kill j (class bit, vector at the time of the kill);
+                    // a block first catches up with the kills of the blocks before it, then its earliest non-zero
+                    // vector kills, is substituted into the rest of ITS block, and so on: one ballot, one count of
+                    // trailing zeros and two lane reads per kill on the critical path.
+                    u32 kbit = 0u;
+                    WT kvec = 0;
+                    // lane i: mask of the i-th oldest class alive (0 beyond the classes in use)
+                    WT cm = lane < nalive0 ? (WT)1 << ordcls : (WT)0;
+                    bool stop = false;
+#pragma unroll
+                    for (int q = 0; q < LPL; ++q) {
+                        if (q >= nq || stop) break;
+                        WT v = ev[q].w[0];
+                        const u32 myk = ek[q];
+                        for (int k = 0; k < nk; ++k) {                 // the kills so far, in their order
+                            const WT m = (WT)1 << rl32(kbit, k);
+                            const WT w = sizeof(WT) == 8 ? (WT)rl64((u64)kvec, k) : (WT)rl32((u32)kvec, k);
+                            if (v & m) v ^= w;
+                        }
+                        u64 nz = __ballot(v != 0);
+                        while (nz) {
+                            if (nk == KMAX) { more = 1; stop = true; break; }
+                            const int src = __builtin_ctzll(nz);
+                            const WT wvw = sizeof(WT) == 8 ? (WT)rl64((u64)v, src) : (WT)rl32((u32)v, src);
+                            // elder rule: the youngest member is the highest lane whose class is in the vector
+                            const u64 ob = __ballot((cm & wvw) != 0);
+                            if (!ob) { status |= TDA_WIN_CLASS_OVERFLOW; stop = true; break; }       // cannot happen: never spin
+                            const int opos = 63 - __builtin_clzll(ob);
+                            const int ybit = (int)rl32((u32)ordcls, opos);
+                            const WT ybm = (WT)1 << ybit;
+                            if (v & ybm) v ^= wvw;                      // (the killer itself becomes zero)
+                            nz = __ballot(v != 0);
+                            // ---- off the critical path ----
+                            const u32 kk = rl32(myk, src);
+                            const float ybirth = __uint_as_float(rl32(__float_as_uint(bky[0]), ybit));
+                            // the class leaves the order: the younger ones move down one lane
+                            const int up = __builtin_amdgcn_update_dpp(0, ordcls, 0x130, 0xF, 0xF, true);     // wave_shl:1 = lane + 1
+                            WT cmup;
+                            if (sizeof(WT) == 8) {
+                                const u32 lo = (u32)__builtin_amdgcn_update_dpp(0, (int)(u32)cm, 0x130, 0xF, 0xF, true);
+                                const u32 hi = (u32)__builtin_amdgcn_update_dpp(0, (int)(u32)((u64)cm >> 32), 0x130, 0xF, 0xF, true);
+                                cmup = (WT)(((u64)hi << 32) | lo);
+                            } else cmup = (WT)(u32)__builtin_amdgcn_update_dpp(0, (int)(u32)cm, 0x130, 0xF, 0xF, true);
+                            if (lane >= opos) { ordcls = up; cm = cmup; }
+                            // lane j keeps kill j: the image of its class under all LATER kills (lanes beyond hold zero)
+                            if (vimg.w[0] & ybm) vimg.w[0] ^= wvw;
+                            if (lane == nk) {
+                                vimg.w[0] = wvw & (WT)~ybm;
+                                mycode = (u32)ybit; myrk = (u32)(r0 + (int)((kk >> 8) & 0xffffu)); mybirth = ybirth;
+                                kbit = (u32)ybit; kvec = wvw;
+                            }
+                            alive[0] &= (WT)~ybm;
+                            ++nk;
+                            PROF_COUNT(10, 1);
+                        }
+                    }
+                } else
                 while (true) {
                     u32 mk = 0xffffffffu;
 #pragma unroll
@@ -1133,6 +1244,7 @@ __device__ void rips_sweep(int n, int E, int Ev, const u16* rank, const u16* ord
                     for (int c = 0; c < W; ++c) shared->alive[c] = (u64)alive[c];
                     shared->k1 = k1; shared->nk = nk; shared->more = more; shared->status = status;
                 }
+                TDA_SOLO_END();
             }
             __syncthreads();
             PROF_MARK(18);
