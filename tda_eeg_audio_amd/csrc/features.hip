@@ -11,36 +11,104 @@
 #include "common.h"
 
 // numpy's pairwise sum over f(lo) .. f(lo+n-1), evaluated redundantly by every lane that
-// calls it (n is tiny: <= a few hundred)
+// calls it (n is tiny: <= a few hundred).  The leaf (n <= 128: every diagram and group of the path) is inlined into
+// its caller -- as a (recursive) call per sum the finishing pass of a step took 1.6x as long.
 template <class F>
-__device__ double np_pairwise_fn(const F& f, int lo, int n)
+__device__ __forceinline__ double np_pairwise_leaf(const F& f, int lo, int n)
 {
     if (n < 8) {
         double res = 0.0;
         for (int i = 0; i < n; ++i) res += f(lo + i);
         return res;
-    } else if (n <= 128) {
-        double r0 = f(lo), r1 = f(lo + 1), r2 = f(lo + 2), r3 = f(lo + 3);
-        double r4 = f(lo + 4), r5 = f(lo + 5), r6 = f(lo + 6), r7 = f(lo + 7);
-        int i;
-        for (i = 8; i < n - (n % 8); i += 8) {
-            r0 += f(lo + i + 0); r1 += f(lo + i + 1); r2 += f(lo + i + 2); r3 += f(lo + i + 3);
-            r4 += f(lo + i + 4); r5 += f(lo + i + 5); r6 += f(lo + i + 6); r7 += f(lo + i + 7);
-        }
-        double res = ((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7));
-        for (; i < n; ++i) res += f(lo + i);
-        return res;
-    } else {
-        int n2 = n / 2;
-        n2 -= n2 % 8;
-        return np_pairwise_fn(f, lo, n2) + np_pairwise_fn(f, lo + n2, n - n2);
     }
+    double r0 = f(lo), r1 = f(lo + 1), r2 = f(lo + 2), r3 = f(lo + 3);
+    double r4 = f(lo + 4), r5 = f(lo + 5), r6 = f(lo + 6), r7 = f(lo + 7);
+    int i;
+    for (i = 8; i < n - (n % 8); i += 8) {
+        r0 += f(lo + i + 0); r1 += f(lo + i + 1); r2 += f(lo + i + 2); r3 += f(lo + i + 3);
+        r4 += f(lo + i + 4); r5 += f(lo + i + 5); r6 += f(lo + i + 6); r7 += f(lo + i + 7);
+    }
+    double res = ((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7));
+    for (; i < n; ++i) res += f(lo + i);
+    return res;
+}
+template <class F>
+__device__ __forceinline__ double np_pairwise_split_uniform(const F& f, int lo_, int n_)        // n > 128 (off the usual path)
+{
+    // numpy halves recursively (left part a multiple of 8) down to leaves of <= 128: the same tree, walked with an
+    // explicit stack.  UNIFORM flavour: every lane of the wave evaluates the same sum, so frame i of the stack lives in LANE i of four
+    // registers (select / v_readlane with the wave-uniform stack pointer): no calls, no scratch memory.
+    const int lo = uni(lo_), n = uni(n_);
+    int vlo = 0, vn = 0, vph = 0, vl0 = 0, vl1 = 0;
+    int sp = 0;
+    const int me = lane_id();
+    double ret = 0.0;
+    vlo = me == 0 ? (lo) : vlo;
+    vn = me == 0 ? (n) : vn;
+    while (sp >= 0) {
+        const int flo = __builtin_amdgcn_readlane(vlo, sp), fn = __builtin_amdgcn_readlane(vn, sp);
+        const int ph = __builtin_amdgcn_readlane(vph, sp);
+        if (fn <= 128) { ret = uni_f64(np_pairwise_leaf(f, flo, fn), 0); --sp; continue; }
+        int n2 = fn / 2;
+        n2 -= n2 % 8;
+        if (ph == 0) {
+            vph = me == sp ? (1) : vph;
+            ++sp;
+            vlo = me == sp ? (flo) : vlo; vn = me == sp ? (n2) : vn;
+            vph = me == sp ? (0) : vph;
+        } else if (ph == 1) {
+            const long long bits = __double_as_longlong(ret);
+            vl0 = me == sp ? ((int)(unsigned)(bits & 0xffffffffll)) : vl0;
+            vl1 = me == sp ? ((int)(unsigned)((unsigned long long)bits >> 32)) : vl1;
+            vph = me == sp ? (2) : vph;
+            ++sp;
+            vlo = me == sp ? (flo + n2) : vlo; vn = me == sp ? (fn - n2) : vn;
+            vph = me == sp ? (0) : vph;
+        } else {
+            const unsigned l0 = (unsigned)__builtin_amdgcn_readlane(vl0, sp), l1 = (unsigned)__builtin_amdgcn_readlane(vl1, sp);
+            ret = __longlong_as_double((long long)(((unsigned long long)l1 << 32) | l0)) + ret;
+            --sp;
+        }
+    }
+    return ret;
+}
+// any-lane flavour (sums and lengths may differ from lane to lane): frames in private arrays, a real call -- used by
+// the small per-group kernels, whose groups have <= 128 members on the whole path
+template <class F>
+__device__ __noinline__ double np_pairwise_split(const F& f, int lo, int n)
+{
+    int slo[26], sn[26], sph[26];
+    double sleft[26];
+    int sp = 0;
+    double ret = 0.0;
+    slo[0] = lo; sn[0] = n; sph[0] = 0; sleft[0] = 0.0;
+    while (sp >= 0) {
+        const int flo = slo[sp], fn = sn[sp];
+        if (fn <= 128) { ret = np_pairwise_leaf(f, flo, fn); --sp; continue; }
+        int n2 = fn / 2;
+        n2 -= n2 % 8;
+        if (sph[sp] == 0) { sph[sp] = 1; ++sp; slo[sp] = flo; sn[sp] = n2; sph[sp] = 0; }
+        else if (sph[sp] == 1) { sleft[sp] = ret; sph[sp] = 2; ++sp; slo[sp] = flo + n2; sn[sp] = fn - n2; sph[sp] = 0; }
+        else { ret = sleft[sp] + ret; --sp; }
+    }
+    return ret;
+}
+template <class F>
+__device__ __forceinline__ double np_pairwise_fn(const F& f, int lo, int n)
+{
+    return n <= 128 ? np_pairwise_leaf(f, lo, n) : np_pairwise_split(f, lo, n);
 }
 
-__device__ double np_pairwise_sum(const double* a, int n, int stride)
+__device__ __forceinline__ double np_pairwise_sum(const double* a, int n, int stride)
 {
     auto f = [=](int i) { return a[(size_t)i * stride]; };
     return np_pairwise_fn(f, 0, n);
+}
+// the same sum and length in every lane of the wave (diagram_finish_kernel)
+__device__ __forceinline__ double np_pairwise_sum_uniform(const double* a, int n)
+{
+    auto f = [=](int i) { return a[i]; };
+    return n <= 128 ? np_pairwise_leaf(f, 0, n) : np_pairwise_split_uniform(f, 0, n);
 }
 
 // ---------------------------------------------------------------------------------
@@ -108,15 +176,26 @@ struct DiagramSets {
     int n_sets;
 };
 
-__global__ void __launch_bounds__(64)
+// Waves of a workgroup never meet: each has its own diagram and its own LDS slice, and the LDS serves the accesses
+// of ONE wave in program order -- a compiler fence is all the synchronisation there is.  (Four diagrams per
+// workgroup because a launch of 3 x 106,200 one-wave workgroups is bound by the dispatcher, not by the work.)
+#define FIN_WAVES 4
+__device__ __forceinline__ void wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+__global__ void __launch_bounds__(64 * FIN_WAVES, 5)
 diagram_finish_kernel(DiagramSets S, int n_dgm, int lds_cap)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    double* b = reinterpret_cast<double*>(smem);    // births | deaths | pers | tmp, lds_cap each
+    const int wv = uni((int)(threadIdx.x >> 6));
+    double* b = reinterpret_cast<double*>(smem) + (size_t)wv * 4 * lds_cap;    // births | deaths | pers | tmp, lds_cap each
     double* d = b + lds_cap;
     double* p = d + lds_cap;
     double* tmp = p + lds_cap;
-    const int set = blockIdx.x / n_dgm, g = blockIdx.x - set * n_dgm;
+    const long long gi = (long long)blockIdx.x * (blockDim.x >> 6) + wv;
+    const int set = (int)(gi / n_dgm), g = (int)(gi - (long long)set * n_dgm);
     if (set >= S.n_sets) return;
     const int cap = S.cap[set];
     const int lane = lane_id();
@@ -130,7 +209,7 @@ diagram_finish_kernel(DiagramSets S, int n_dgm, int lds_cap)
     double* rb = reorder ? p : b;
     double* rd = reorder ? tmp : d;
     for (int i = lane; i < k; i += 64) { rb[i] = rows[2 * i]; rd[i] = rows[2 * i + 1]; }
-    __syncthreads();
+    wave_sync();
     if (reorder) {
         for (int i = lane; i < k; i += 64) {
             const double bi = rb[i], di = rd[i];
@@ -142,7 +221,7 @@ diagram_finish_kernel(DiagramSets S, int n_dgm, int lds_cap)
             b[pos] = bi; d[pos] = di;
             if (pos != i) { rows[2 * pos] = bi; rows[2 * pos + 1] = di; }
         }
-        __syncthreads();
+        wave_sync();
     }
     if (!feat) return;
     // compact finite rows in place, preserving order (utils.py:146-147): row i moves to pos <= i, and every lane
@@ -155,12 +234,12 @@ diagram_finish_kernel(DiagramSets S, int n_dgm, int lds_cap)
         if (valid) { bi = b[i]; di = d[i]; fin = isfinite(bi) && isfinite(di); }
         const u64 bal = __ballot(fin);
         const int pos = m + __popcll(bal & ((1ull << lane) - 1ull));
-        __syncthreads();
+        wave_sync();
         if (fin) { b[pos] = bi; d[pos] = di; p[pos] = di - bi; }
         m += __popcll(bal);
         ness += __popcll(__ballot(valid && !fin));
     }
-    __syncthreads();
+    wave_sync();
     double out[TDA_N_FEATURES];
 #pragma unroll
     for (int i = 0; i < TDA_N_FEATURES; ++i) out[i] = 0.0;
@@ -169,13 +248,13 @@ diagram_finish_kernel(DiagramSets S, int n_dgm, int lds_cap)
         out[0] = (double)m;
         const double* arr[3] = {b, d, p};
         for (int q = 0; q < 3; ++q) {
-            const double mean = np_pairwise_sum(arr[q], m, 1) / (double)m;
+            const double mean = np_pairwise_sum_uniform(arr[q], m) / (double)m;
             out[2 + 2 * q] = mean;
             if (m > 1) {
-                __syncthreads();
+                wave_sync();
                 for (int i = lane; i < m; i += 64) { const double z = arr[q][i] - mean; tmp[i] = z * z; }
-                __syncthreads();
-                out[3 + 2 * q] = sqrt(np_pairwise_sum(tmp, m, 1) / (double)m);
+                wave_sync();
+                out[3 + 2 * q] = sqrt(np_pairwise_sum_uniform(tmp, m) / (double)m);
             }
         }
         double mx = -INFINITY;
@@ -183,10 +262,10 @@ diagram_finish_kernel(DiagramSets S, int n_dgm, int lds_cap)
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) { const double o = __shfl_xor(mx, off, 64); mx = o > mx ? o : mx; }
         out[8] = mx;
-        const double tot = np_pairwise_sum(p, m, 1);
+        const double tot = np_pairwise_sum_uniform(p, m);
         out[9] = tot;
         if (m > 1 && tot > 0.0) {
-            __syncthreads();
+            wave_sync();
             // pn = pers/sum; keep pn > 0 in order (utils.py:161-163)
             int c = 0;
             for (int i0 = 0; i0 < m; i0 += 64) {
@@ -199,8 +278,8 @@ diagram_finish_kernel(DiagramSets S, int n_dgm, int lds_cap)
                 if (pos) tmp[at] = pn * log(pn + 1e-10);
                 c += __popcll(bal);
             }
-            __syncthreads();
-            out[10] = -np_pairwise_sum(tmp, c, 1) / log((double)m + 1e-10);
+            wave_sync();
+            out[10] = -np_pairwise_sum_uniform(tmp, c) / log((double)m + 1e-10);
         }
     }
     if (lane < TDA_N_FEATURES) {
@@ -435,11 +514,14 @@ tda_status launch_diagram_finish(tda_ctx* ctx, const tda_diagram_set* sets, int 
         }
     }
     S.n_sets = n_sets;
-    const size_t lds = (size_t)cap * 4 * 8;
+    int nw = FIN_WAVES;                                  // diagrams per workgroup: fewer when the slices are large
+    while (nw > 1 && (size_t)cap * 4 * 8 * nw > 32 * 1024) nw >>= 1;
+    const size_t lds = (size_t)cap * 4 * 8 * nw;
     if (lds > 48 * 1024)
         TDA_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(diagram_finish_kernel),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(diagram_finish_kernel, dim3((unsigned)n_sets * (unsigned)n_dgm), dim3(64), lds, st, S, n_dgm, cap);
+    const long long n_all = (long long)n_sets * n_dgm;
+    hipLaunchKernelGGL(diagram_finish_kernel, dim3((unsigned)((n_all + nw - 1) / nw)), dim3(64 * nw), lds, st, S, n_dgm, cap);
     TDA_HIP(ctx, hipGetLastError());
     return TDA_OK;
 }

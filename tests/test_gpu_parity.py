@@ -337,6 +337,33 @@ def test_features_and_aggregate_on_real_diagrams(ctx):
             assert np.array_equal(agg[s, 4 * f:4 * f + 4], exp), (s, f)
 
 
+def test_pairwise_sums_beyond_128_terms(ctx):
+    """numpy sums more than 128 terms by recursive halving (left half a multiple of 8); the kernels walk the same tree
+    with a stack kept across the lanes of the wave: diagrams of 129..2000 rows and groups of 129..1111 windows, the
+    sums bit-equal to np.mean / np.std / np.sum."""
+    rng = np.random.default_rng(12)
+    dg = []
+    for k in (129, 130, 136, 255, 256, 257, 700, 1025, 2000):
+        b = rng.random(k)
+        d = np.stack([b, b + rng.random(k)], axis=1).astype(np.float32).astype(np.float64)
+        d[rng.integers(0, k, 3), 1] = np.inf
+        dg.append(d)
+    rows, cnt = engine.pack_diagrams(dg)
+    feat = engine.features_batch(rows, cnt, ctx=ctx)
+    for i, d in enumerate(dg):
+        ref = port.features(d)
+        assert np.array_equal(feat[i, :10], ref[:10]), len(d)
+        assert np.allclose(feat[i, 10], ref[10], rtol=1e-12, atol=0)
+    f0 = rng.standard_normal((129 + 300 + 1111 + 5, 11)); f1 = rng.standard_normal(f0.shape)
+    seg = np.array([0, 129, 429, 1540, 1545], np.int32)
+    agg = engine.aggregate_batch(f0, f1, seg, ctx=ctx)
+    for s_ in range(4):
+        a, b = seg[s_], seg[s_ + 1]
+        for f in range(11):
+            exp = [np.mean(f0[a:b, f]), np.std(f0[a:b, f]), np.mean(f1[a:b, f]), np.std(f1[a:b, f])]
+            assert np.array_equal(agg[s_, 4 * f:4 * f + 4], exp), (s_, f)
+
+
 # ------------------------------------------------------------------ Wasserstein
 def test_wasserstein_known_answers(ctx):
     A = np.array([[0.0, 1.0]]); B = np.array([[0.0, 2.0]])
