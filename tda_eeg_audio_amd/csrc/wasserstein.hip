@@ -73,7 +73,7 @@ __global__ void __launch_bounds__(64)
 wasserstein_kernel(const double* __restrict__ dgm_a, const int* __restrict__ cnt_a, int cap_a,
                    const double* __restrict__ dgm_b, const int* __restrict__ cnt_b, int cap_b,
                    const int* __restrict__ idx_a, const int* __restrict__ idx_b, int n_pairs,
-                   int max_rows, int max_cols, int mat_entries,
+                   int max_rows, int max_cols,
                    double* __restrict__ out, int* __restrict__ status)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -82,7 +82,7 @@ wasserstein_kernel(const double* __restrict__ dgm_a, const int* __restrict__ cnt
     const int lane = lane_id();
     unsigned long long wt0 = WCLK();
     (void)wt0;
-    // LDS: row points (b,d,s) | col points (b,d,t) | u[rows] | cost matrix (optional)
+    // LDS: row points (b,d,s) | u[rows] | col points (b,d,t) | owner[cols] | |y|^2 of the columns (1-D path)
     double* rb = reinterpret_cast<double*>(smem);
     double* rd = rb + max_rows;
     double* rs = rd + max_rows;
@@ -91,7 +91,7 @@ wasserstein_kernel(const double* __restrict__ dgm_a, const int* __restrict__ cnt
     double* cd = cb + max_cols;
     double* ct = cd + max_cols;
     int* owner = reinterpret_cast<int*>(ct + max_cols);                 // max_cols ints (padded to 8 B)
-    double* G = ct + max_cols + ((max_cols + 1) >> 1);                  // mat_entries doubles when the pair fits
+    double* G = ct + max_cols + ((max_cols + 1) >> 1);                  // max_cols doubles
 
     const int ia = idx_a ? idx_a[pr] : pr;
     const int ib = idx_b ? idx_b[pr] : pr;
@@ -113,7 +113,6 @@ wasserstein_kernel(const double* __restrict__ dgm_a, const int* __restrict__ cnt
     // rows = smaller diagram
     const bool a_is_row = Me <= Ne;
     const int R = a_is_row ? Me : Ne, Cn = a_is_row ? Ne : Me;
-    const bool use_matrix = R * Cn <= mat_entries;     // per pair: the cost matrix lives in LDS when it fits
     const int cw_used = (Cn + 63) >> 6;                // column slots per lane actually in use
     if (R > max_rows || Cn > max_cols || Cn > 64 * CW) {
         if (lane == 0) { out[pr] = __longlong_as_double(0x7ff8000000000000ll); status[pr] = TDA_WIN_NOT_CONVERGED; }
@@ -157,9 +156,6 @@ wasserstein_kernel(const double* __restrict__ dgm_a, const int* __restrict__ cnt
         const double g = cfull(i, j) - rs[i] - ct[j];
         return g < 0.0 ? g : 0.0;
     };
-    if (use_matrix) {
-        for (int e = lane; e < R * Cn; e += 64) { const int i = e / Cn, j = e - i * Cn; G[e] = gain(i, j); }
-    }
     for (int i = lane; i < R; i += 64) ru[i] = 0.0;
     __syncthreads();
     WPROF(0, WCLK() - wt0); wt0 = WCLK();
@@ -187,19 +183,15 @@ wasserstein_kernel(const double* __restrict__ dgm_a, const int* __restrict__ cnt
         if (ok) {
             double cur = 0.0, nb1 = 0.0, nb2 = 0.0;      // own F, neighbour row's F one / two steps ago
             const int nsteps1d = R + Cn - 1;
-            // gains on the fly (a 46 x 121 H0 pair does not fit the matrix budget): the row's part of sklearn's
-            // expansion is a per-lane constant, the column's |y|^2 is tabulated once in the idle matrix area -- the
-            // same operations in the same order as ws_cost(), 40 instead of 58 instructions per cell
-            const bool tab = !use_matrix && Cn <= mat_entries;
-            if (tab) {
-                for (int j = lane; j < Cn; j += 64) G[j] = cb[j] * cb[j] + cd[j] * cd[j];
-                __syncthreads();
-            }
+            // gains on the fly: the row's part of sklearn's expansion is a per-lane constant, the column's |y|^2 is
+            // tabulated once -- the same operations in the same order as ws_cost(), 40 instead of 58 instructions per cell
+            for (int j = lane; j < Cn; j += 64) G[j] = cb[j] * cb[j] + cd[j] * cd[j];
+            __syncthreads();
             const int li = lane < R ? lane : 0;
             const double r_b = rb[li], r_d = rd[li], r_s = rs[li], r_n = r_b * r_b + r_d * r_d;
             auto gain1d = [&](int j) -> double {
                 const double c_b = cb[j], c_d = cd[j];
-                const double c_n = tab ? G[j] : c_b * c_b + c_d * c_d;
+                const double c_n = G[j];
                 const double dot = fma(r_d, c_d, r_b * c_b);            // = fma(ad, bd, ab * bb) either way round
                 double d2 = -2.0 * dot;
                 d2 += a_is_row ? r_n : c_n;                             // |x|^2 of the FIRST diagram's point, then the second's
@@ -216,7 +208,7 @@ wasserstein_kernel(const double* __restrict__ dgm_a, const int* __restrict__ cnt
                 nb2 = nb1;
                 nb1 = __hiloint2double(hi, lo);
                 if (lane < R && j0 >= 0 && j0 < Cn) {
-                    const double g = use_matrix ? G[lane * Cn + j0] : gain1d(j0);
+                    const double g = gain1d(j0);
                     const double up = nb1;                          // F[row][j0+1] of the row above
                     const double dg = (j0 == 0 ? 0.0 : nb2) + g;    // F[row above][j0] + g
                     double m = up < cur ? up : cur;                 // cur still holds F[row+1][j0] (left)
@@ -265,7 +257,7 @@ wasserstein_kernel(const double* __restrict__ dgm_a, const int* __restrict__ cnt
                 int j = r < Cn ? r : 0;
 #pragma unroll 4
                 for (int t = 0; t < Cn; ++t) {
-                    const double g = use_matrix ? G[r * Cn + j] : gain(r, j);
+                    const double g = gain(r, j);
                     if (g < mn) { mn = g; arg = j; }
                     j = (j + 1 == Cn) ? 0 : j + 1;
                 }
@@ -306,7 +298,7 @@ wasserstein_kernel(const double* __restrict__ dgm_a, const int* __restrict__ cnt
                 if (c >= cw_used) break;
                 const int j = lane + 64 * c;
                 const int jc = j < Cn ? j : Cn - 1;
-                gg[c] = use_matrix ? G[i0 * Cn + jc] : gain(i0, jc);
+                gg[c] = gain(i0, jc);
             }
 #pragma unroll
             for (int c = 0; c < CW; ++c) {
@@ -424,16 +416,10 @@ tda_status launch_wasserstein(tda_ctx* ctx, const double* dgm_a, const int* cnt_
     const int lo = cap_a < cap_b ? cap_a : cap_b, hi = cap_a < cap_b ? cap_b : cap_a;
     const int max_rows = lo, max_cols = hi;
     if (max_cols > 512) TDA_FAIL(ctx, TDA_ERR_UNSUPPORTED, "diagrams with more than 512 rows are not supported");
-    const size_t vec_bytes = (size_t)(4 * max_rows + 3 * max_cols + ((max_cols + 1) >> 1)) * 8;
-    const size_t mat_bytes = (size_t)max_rows * max_cols * 8;
-    // LDS budget for the per-pair cost matrix: whole matrix if small, else 16 KB (2048 entries: a 45 x 45 H1 pair;
-    // H0 pairs have equal births and take the 1-D path without a matrix); pairs that do not fit evaluate costs on
-    // the fly.  A small footprint matters more than the rare big pair: the workgroups of this kernel (one wave
-    // each) have to find room next to the Rips kernels of the other batches in flight.
-    const size_t cap_budget = 16 * 1024;
-    size_t mat_budget = mat_bytes <= cap_budget ? mat_bytes : cap_budget;
-    const int mat_entries = (int)(mat_budget / 8);
-    const size_t lds = vec_bytes + mat_budget;
+    // No cost matrix in LDS: gains are evaluated where they are needed.  A per-pair matrix (16 KB for a 45 x 45 H1
+    // pair) left room for 5-7 one-wave workgroups per CU; without it the H0 pairs of a pass take 1.7 instead of 2.9 ms
+    // and the H1 pairs 0.73 instead of 1.17 ms (latency-bound solver: residency matters more than the re-evaluation).
+    const size_t lds = (size_t)(4 * max_rows + 4 * max_cols + ((max_cols + 1) >> 1)) * 8;
 #define WS_LAUNCH(CWV)                                                                                         \
     do {                                                                                                       \
         auto kern = wasserstein_kernel<CWV>;                                                                   \
@@ -441,7 +427,7 @@ tda_status launch_wasserstein(tda_ctx* ctx, const double* dgm_a, const int* cnt_
             TDA_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                              \
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));           \
         hipLaunchKernelGGL(kern, dim3(n_pairs), dim3(64), lds, st, dgm_a, cnt_a, cap_a, dgm_b, cnt_b, cap_b,   \
-                           idx_a, idx_b, n_pairs, max_rows, max_cols, mat_entries, out, status);                \
+                           idx_a, idx_b, n_pairs, max_rows, max_cols, out, status);                \
     } while (0)
     if (max_cols <= 128) WS_LAUNCH(2);
     else if (max_cols <= 256) WS_LAUNCH(4);
