@@ -812,24 +812,34 @@ __device__ void rips_sweep(int n, int E, int Ev, const u16* rank, const u16* ord
             psi[tab] = base;
             pending = false;
         }
-        if (!pending) done[tid] = 1;        // candidates, idle lanes and the lanes above are settled
+        // The rest waits for its two edges, WITHOUT barriers: dependencies point at earlier edges of the chunk only,
+        // every wave of the workgroup is resident, and the LDS serves the accesses of a wave in program order -- so an
+        // owner writes its vector, then its flag, and a reader that has seen the flag reads the vector.  A wave polls
+        // until its own lanes are settled (a chain inside the wave advances one link per trip); the barrier after the
+        // loop is the only one of the phase (it used to be two per dependency level: 12 to 29 levels per window).
+        volatile unsigned char* vdone = done;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");       // (births and the lanes just above wrote their vectors)
+        if (!pending) vdone[tid] = 1;        // candidates, idle lanes and the lanes above are settled
 #ifdef TDA_PROFILE
         if (pending) atomicAdd(&prof_lds[33], 1ull);
         PROF_COUNT(34, 1);
 #endif
-        // rounds for the rest: a lane is ready when both dependencies are settled
-        while (wg_any<NT>(vote, pending)) {
+        while (__ballot(pending)) {
             PROF_COUNT(32, 1);
             bool ready = false;
-            if (pending) ready = (q1 < 0 || done[q1]) && (q2 < 0 || done[q2]);
-            __syncthreads();                 // all flag reads of this round precede its flag writes
-            if (pending && ready) {
+            if (pending) ready = (q1 < 0 || vdone[q1]) && (q2 < 0 || vdone[q2]);
+            const u64 rbal = __ballot(ready);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            if (ready) {
                 base = pxor(psi[d1], psi[d2]);
                 psi[tab] = base;
-                done[tid] = 1;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                vdone[tid] = 1;
                 pending = false;
             }
+            if (!rbal) __builtin_amdgcn_s_sleep(1);                  // nothing to do this trip: leave the issue slots to the others (0 / 1 / 2 / 4: no difference measured)
         }
+        __syncthreads();
         PROF_MARK(6);
         PROF_STOP(15, out_k0 = k0; out_k1 = k1; out_status = 0);
         // ---- d. the other triangles of every apparent edge ----
@@ -1126,7 +1136,6 @@ __device__ void rips_sweep(int n, int E, int Ev, const u16* rank, const u16* ord
                             }
                             alive[0] &= (WT)~ybm;
                             ++nk;
-                            PROF_COUNT(10, 1);
                         }
                     }
                 } else
@@ -1218,9 +1227,9 @@ __device__ void rips_sweep(int n, int E, int Ev, const u16* rank, const u16* ord
                     for (int c = 0; c < W; ++c)
                         if (c == ycw) alive[c] &= (WT)~((WT)1 << ybit);
                     ++nk;
-                    PROF_COUNT(10, 1);
                 }
                 PROF_MARK(31);
+                PROF_COUNT(10, nk);                                  // (counted here: a counter update per kill would be a third of the loop)
                 if (FTAB) {
                     // diagram rows of this round, one kill per lane; the image table for the rewrite
                     const bool mine_ok = lane < nk;

@@ -11,6 +11,8 @@ ctx = _lib.get_ctx(0)
 lib = ctx.lib
 buf = (C.c_ulonglong * 48)()
 NW = int(sys.argv[1]) if len(sys.argv) > 1 else 256      # 256 = one workgroup per CU (latency); 4096: CUs shared
+if os.environ.get("TDA_CLASS_WORDS"):                      # e.g. "1,1": the first-pass widths bench.py uses
+    ctx.set_class_words(*[int(x) for x in os.environ["TDA_CLASS_WORDS"].split(",")])
 W_ = synth.eeg_windows(NW, seed=3)
 dist_ = engine.corr_dist_batch(W_, want_corr=False, ctx=ctx)
 engine.rips_dm_batch(dist_, ctx=ctx); lib.tda_profile_read(buf, 1)
