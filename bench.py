@@ -8,7 +8,8 @@ Workload (default `--workload corpus`, BASELINE.json configs[2] + configs[4]): t
 (scripts/tda_eeg_audio_comparison.py:39,77-80; results/eeg_audio_tda_detailed.csv has 7,080 rows of 15 windows) --
 dealt over the N ranks by whole recordings (dist.shard_recordings): STRONG scaling.  A step = ONE pass of the
 per-window hot path over the rank's share, resident in HBM (10 GB of float64 windows at N = 1, so nothing is served
-by the 256 MiB Infinity Cache): per window corr->dist, Rips(EEG 47x47), tau per recording-band, Takens+Rips(audio,
+by the 256 MiB Infinity Cache), all five bands of the share as ONE batch per pass (`--per-band`: one batch per
+band), three passes in flight on their own streams as HIP graphs: per window corr->dist, Rips(EEG 47x47), tau per recording-band, Takens+Rips(audio,
 23..123 points over the five bands), Wasserstein H0 and H1, H1/H0 features, the per-recording reductions, and ONE
 all-gather of the (n_rec, 5 x 48) result rows per pass (RCCL over xGMI) inside the timed region -- what replaces
 run_analysis' serial loop (cmp:131-138) and the partial-file merge of scripts/tda_eeg_classification_v2.py:608-638.
@@ -222,7 +223,7 @@ def main():
             return t[s][0].elapsed_time(t[s][1])
         except Exception:                        # stage not on this path (fused / two-kernel EEG chain)
             return 0.0
-    stage_ms = {s: sum(_ms(t, s) for t in ev_log) for s in pipeline.STAGES}    # per pass, band batches one at a time
+    stage_ms = {s: sum(_ms(t, s) for t in ev_log) for s in pipeline.STAGES}    # per pass, every stage alone on the GPU
     stage_ms = {s: v for s, v in stage_ms.items() if v > 0.0}
     event_ms = [ctx.elapsed_ms(a, b) for a, b in probes]
     try:
@@ -326,7 +327,7 @@ def main():
                        "batches_rerun_with_full_ladder": lanes.repairs,
                        "result_rows_finite_frac": round(finite_frac, 6),
                        "data_generation_s": round(t_gen, 2)},
-            "stage_ms": {s: round(v, 4) for s, v in stage_ms.items()},     # one eager pass, band batches one at a time
+            "stage_ms": {s: round(v, 4) for s, v in stage_ms.items()},     # one eager pass, every stage alone on the GPU
             "host_loop_ms_per_step": round(t_enq / args.steps * 1e3, 4),
             "roofline": {"bound": "hbm", "kernel": "rips_cloud_kernel<512, 1, unsigned int> (stage rips_audio)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -340,7 +341,7 @@ def main():
                                  "average over every launch of the timed region of (first workgroup start .. last "
                                  "workgroup end), stamped by the kernel itself (100 MHz wall clock) -- the interval "
                                  "rocprofv3 --kernel-trace reports; `achieved` uses it.  event_ms: HIP events around the "
-                                 "same launch on its stream, band batches alone (eager warm-up pass)"},
+                                 "same launch on its stream, alone on the GPU (eager warm-up pass)"},
             "roofline_lds": prof("r02_lds_roofline.json"),
         }
         fp = extras.get("features_pass")

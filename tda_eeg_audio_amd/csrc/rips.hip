@@ -552,7 +552,7 @@ __device__ void rips_sweep(int n, int E, int Ev, const u16* rank, const u16* ord
         for (int w = 0; w < NT / 64; ++w) ncand += __builtin_popcountll(cand[w]);
         int btot = 0;                                            // births of this chunk
         if (ncand > 0) {                                         // (a chunk without candidates has no phase b at all)
-        const bool par = ncand > 24;
+        const bool par = ncand > 24;                             // (48: the same, 96: 1 % slower)
         const int lblA0 = compA, lblB0 = compB;                  // labels at chunk start (wave 0)
         int qpar = NT;                                           // cut of the chunk found by the parallel path
         if (par) {

@@ -1,11 +1,13 @@
 #!/bin/bash
 # Collect the rocprofv3 evidence that profiles/ holds (run on the GPU box from the repo root):
 #   tools/collect_profiles.sh <tag>        e.g. r02
-# 1. per-kernel time: --kernel-trace --stats of the default bench command (corpus workload, 10 timed passes)
+# 1. per-kernel time: --kernel-trace --stats of the default bench workload (corpus, 10 timed passes; no secondary legs, so
+#    that the launches of the dominant kernel are exactly the ones bench.py's own probe averages: kernel_ms_all_launches)
 # 2. HBM bytes: --pmc FETCH_SIZE and --pmc WRITE_SIZE in SEPARATE passes (kernel-trace only, as the MI355X guide
 #    prescribes), one band batch in flight and eager launches so that launches map 1:1 to stages
 # 3. SQ counters of the Rips kernels (what binds them is LDS / issue, not HBM): three more --pmc passes, 8 SQ slots each
-# Passes 2-3 run a reduced corpus (236 recordings = 3,540 windows per band batch, 13.8 rounds of the audio kernel):
+# Passes 2-3 run a reduced corpus, one batch per band (236 recordings = 3,540 windows per launch, 6.9 rounds of the audio
+# kernel at two workgroups per CU):
 # the counters are per-launch sums and the figures reported are per window or ratios.
 # The program sits directly after `--` in every pass.  Summaries go to gpurun_out/<tag>_*; copy what is to be judged
 # into profiles/.
@@ -14,8 +16,8 @@ TAG=${1:-r02}
 OUT=gpurun_out
 mkdir -p $OUT
 export TMPDIR=/tmp
-SMALL="bench.py --no-cpu --no-extras --recordings 236 --steps 2 --warmup 1 --lanes 1 --no-graph"
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_stats -o stats -- python3 bench.py --no-cpu --steps 10 --warmup 2 > $OUT/${TAG}_bench_under_rocprof.json 2> $OUT/prof_stats.err
+SMALL="bench.py --no-cpu --no-extras --recordings 236 --steps 2 --warmup 1 --lanes 1 --no-graph --per-band"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_stats -o stats -- python3 bench.py --no-cpu --no-extras --steps 10 --warmup 2 > $OUT/${TAG}_bench_under_rocprof.json 2> $OUT/prof_stats.err
 echo "stats pass done"
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/prof_fetch -o fetch -- python3 $SMALL > /dev/null 2> $OUT/prof_fetch.err
 echo "FETCH_SIZE pass done"
