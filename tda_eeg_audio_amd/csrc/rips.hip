@@ -462,6 +462,9 @@ __device__ void rips_sweep(int n, int E, int Ev, const u16* rank, const u16* ord
     int clen = NT;
     int ordcls = 0;                              // wave 0, one class word: lane i holds the i-th oldest class alive
     int cov_next = tid;                          // coverage check: first edge of this thread's residue class not yet seen covered
+#ifdef TDA_PROFILE
+    int prof_rneed = 0;
+#endif
     PROF_RESUME();
     for (int r0 = 0; r0 < Ev && !status; r0 += clen) {
         clen = NT;
@@ -783,6 +786,9 @@ __device__ void rips_sweep(int n, int E, int Ev, const u16* rank, const u16* ord
         for (int c = 0; c < W; ++c) quiet = quiet && alive[c] == 0;
         u32* lcnt = reinterpret_cast<u32*>(misc + MISC_MIN);         // list header: [0] entries, [1] earliest key
         if (quiet) PROF_COUNT(24, 1);
+#ifdef TDA_PROFILE
+        if (!quiet) prof_rneed = r0 + clen;          // class vectors are needed for the ranks below this
+#endif
         if (!quiet) {
         // ---- c. apparent edges: psi[e] = psi[a,v*] ^ psi[b,v*] ----
         // apex of the triangle that kills the edge at once: ANY common neighbour is valid (the other
@@ -1384,6 +1390,10 @@ __device__ void rips_sweep(int n, int E, int Ev, const u16* rank, const u16* ord
         }
         PROF_MARK(7);
     }
+#ifdef TDA_PROFILE
+    PROF_COUNT(36, prof_rneed > 4096 ? 1 : 0); PROF_COUNT(37, prof_rneed > 4608 ? 1 : 0); PROF_COUNT(38, prof_rneed > 5120 ? 1 : 0);
+    PROF_COUNT(39, prof_rneed); PROF_COUNT(40, Ev);
+#endif
     // essential classes
     const int ncomp = n - merges;
     for (int i = 0; i < ncomp; ++i) {

@@ -21,7 +21,7 @@ v = np.array(list(buf), dtype=np.float64); n = v[8]
 print(f"eeg: windows={int(n)} E/win={v[9]/n:.0f} cycles/win: keygen={v[0]/n:.0f} sort={v[1]/n:.0f} unpack={v[2]/n:.0f} "
       f"sweep={v[3]/n:.0f} [mask={v[4]/n:.0f} candidates={v[5]/n:.0f} deps={v[6]/n:.0f} scan+kills={v[7]/n:.0f}] kills/win={v[10]/n:.1f} "
       f"list rounds/win={v[11]/n:.1f} entries/round={v[12]/max(v[11],1):.1f} overflow rounds/win={v[13]/n:.2f}\n     phase d: closure={v[16]/n:.0f} list={v[17]/n:.0f} reduce={(v[18]+v[30]+v[31])/n:.0f} (setup {v[30]/n:.0f} + kill loop {v[31]/n:.0f} + rows/barrier {v[18]/n:.0f}) table={v[19]/n:.0f} rest={v[7]/n:.0f}; candidates walked/win={v[20]/n:.0f} [phase b: to barrier={v[21]/n:.0f} walk={v[22]/n:.0f} publish={v[5]/n:.0f}] chunks/win={v[23]/n:.1f} shortened={v[14]/n:.2f} quiet={v[24]/n:.1f} ended early={v[25]/n:.2f}; triangles to test/win={v[27]/n:.0f} on {v[29]/n:.0f} of {v[28]/n:.0f} apparent edges; dependency rounds/win={v[32]/n:.1f} for {v[33]/n:.0f} in-chunk dependent edges in {v[34]/n:.1f} busy chunks; edges skipped to the next candidate/win={v[35]/n:.0f}")
-for band in ["beta", "delta"]:
+for band in (os.environ.get("TDA_PROFILE_BANDS", "beta,delta").split(",")):
     wins = synth.audio_windows(NW, band, seed=1)
     tau = engine.tau_batch(wins[:1], 125, ctx=ctx)[0]
     engine.takens_rips_batch(wins, tau, ctx=ctx)
@@ -32,7 +32,8 @@ for band in ["beta", "delta"]:
     n = v[8]
     print(f"audio {band} tau={tau}: windows={int(n)} E/win={v[9]/n:.0f} cycles/win: keygen={v[0]/n:.0f} sort={v[1]/n:.0f} "
           f"unpack={v[2]/n:.0f} sweep={v[3]/n:.0f} [mask={v[4]/n:.0f} candidates={v[5]/n:.0f} deps={v[6]/n:.0f} scan+kills={v[7]/n:.0f}] kills/win={v[10]/n:.1f} "
-          f"list rounds/win={v[11]/n:.1f} entries/round={v[12]/max(v[11],1):.1f} overflow rounds/win={v[13]/n:.2f}\n     phase d: closure={v[16]/n:.0f} list={v[17]/n:.0f} reduce={(v[18]+v[30]+v[31])/n:.0f} (setup {v[30]/n:.0f} + kill loop {v[31]/n:.0f} + rows/barrier {v[18]/n:.0f}) table={v[19]/n:.0f} rest={v[7]/n:.0f}; candidates walked/win={v[20]/n:.0f} [phase b: to barrier={v[21]/n:.0f} walk={v[22]/n:.0f} publish={v[5]/n:.0f}] chunks/win={v[23]/n:.1f} shortened={v[14]/n:.2f} quiet={v[24]/n:.1f} ended early={v[25]/n:.2f}; triangles to test/win={v[27]/n:.0f} on {v[29]/n:.0f} of {v[28]/n:.0f} apparent edges; dependency rounds/win={v[32]/n:.1f} for {v[33]/n:.0f} in-chunk dependent edges in {v[34]/n:.1f} busy chunks; edges skipped to the next candidate/win={v[35]/n:.0f}")
+          f"list rounds/win={v[11]/n:.1f} entries/round={v[12]/max(v[11],1):.1f} overflow rounds/win={v[13]/n:.2f}\n     phase d: closure={v[16]/n:.0f} list={v[17]/n:.0f} reduce={(v[18]+v[30]+v[31])/n:.0f} (setup {v[30]/n:.0f} + kill loop {v[31]/n:.0f} + rows/barrier {v[18]/n:.0f}) table={v[19]/n:.0f} rest={v[7]/n:.0f}; candidates walked/win={v[20]/n:.0f} [phase b: to barrier={v[21]/n:.0f} walk={v[22]/n:.0f} publish={v[5]/n:.0f}] chunks/win={v[23]/n:.1f} shortened={v[14]/n:.2f} quiet={v[24]/n:.1f} ended early={v[25]/n:.2f}; triangles to test/win={v[27]/n:.0f} on {v[29]/n:.0f} of {v[28]/n:.0f} apparent edges; dependency rounds/win={v[32]/n:.1f} for {v[33]/n:.0f} in-chunk dependent edges in {v[34]/n:.1f} busy chunks; edges skipped to the next candidate/win={v[35]/n:.0f}"
+          f"\n     ranks whose class vectors are needed/win={v[39]/n:.0f} of Ev={v[40]/n:.0f}; windows needing > 4096 / 4608 / 5120: {v[36]/n:.4f} / {v[37]/n:.4f} / {v[38]/n:.4f}")
 
 # ---- Wasserstein phases on pipeline diagrams ----
 W = synth.eeg_windows(256, seed=3)
