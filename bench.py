@@ -47,6 +47,7 @@ ALG_BYTES = {
     "wasserstein": 2700 + 8,                          # <= 2.7 KB/pair
 }
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+VALU_CLOCK_HZ = 2.4e9     # MI355X_MICROARCH.md: peak engine clock
 
 
 def parse_args():
@@ -344,6 +345,17 @@ def main():
                                  "same launch on its stream, alone on the GPU (eager warm-up pass)"},
             "roofline_lds": prof("r02_lds_roofline.json"),
         }
+        vp = (line["roofline_lds"] or {}).get("valu_per_window")
+        if vp and args.workload == "corpus":
+            # the step as a whole against the vector-issue roof: a wave64 instruction occupies its SIMD for 4 cycles
+            peak = world * 256 * 4 * VALU_CLOCK_HZ / 4.0
+            ach = vp["total"] * value
+            line["roofline_valu"] = {"bound": "valu_issue", "achieved": ach / 1e9, "peak": peak / 1e9,
+                                     "unit": "G wave-instructions/s", "frac": ach / peak,
+                                     "valu_wave_instructions_per_window": vp["total"],
+                                     "note": "instructions per window pair from the committed SQ_INSTS_VALU counters "
+                                             "(profiles/r02_sq_counters.json, every kernel of the step), rate from this "
+                                             "run; peak = CUs x 4 SIMDs x 2.4 GHz / 4 cycles per wave64 instruction"}
         fp = extras.get("features_pass")
         if fp:                                   # secondary: the one HBM-streaming kernel of the step
             nw, ms = fp.pop("eeg_kernel_windows"), fp.pop("eeg_kernel_ms")

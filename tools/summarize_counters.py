@@ -34,7 +34,7 @@ for d in sorted(glob.glob(os.path.join(out, "pmc_sq*"))):
 res = {}
 for k, c in acc.items():
     if not any(s in k for s in ("rips_", "corr_dist", "wasserstein", "eeg_", "features", "tau_kernel", "recording_rows",
-                                "h1_order")):
+                                "h1_order", "diagram_finish")):
         continue
     res[k] = {"launches": max(launches[k].values()), **{n: v for n, v in sorted(c.items())}}
 json.dump(res, open(os.path.join(out, f"{tag}_sq_counters.json"), "w"), indent=1)
@@ -72,5 +72,14 @@ lds = {"bound": "lds/issue", "unit": "B/clk/CU", "peak": 128.0,
        "source": f"profiles/{tag}_sq_counters.json (rocprofv3 --pmc, tools/collect_profiles.sh)",
        "rips_cloud": roof("rips_cloud_kernel<512, 1, unsigned int, false"), "rips_dm": roof("rips_dm_kernel<256, 1, 1"),
        "eeg_fused": roof("eeg_window_kernel<3, false, 1, false")}
+# vector wave-instructions per window pair of the step, kernel by kernel (the audio kernel runs 8 waves per window:
+# its wave count gives the windows these passes processed)
+cloud = next((c for k, c in res.items() if "rips_cloud_kernel<512, 1, unsigned int, false" in k), None)
+if cloud and cloud.get("SQ_WAVES") and cloud.get("SQ_INSTS_VALU"):
+    n_win = cloud["SQ_WAVES"] / 8.0
+    per = {k: round(c["SQ_INSTS_VALU"] / n_win, 1) for k, c in res.items() if c.get("SQ_INSTS_VALU")}
+    lds["valu_per_window"] = {"windows_profiled": int(n_win), "by_kernel": per, "total": round(sum(per.values()), 1),
+                              "note": "SQ_INSTS_VALU (wave-instructions) of every kernel of the step divided by the window "
+                                      "pairs processed; bench.py turns it into `roofline_valu` with its own pass time"}
 json.dump(lds, open(os.path.join(out, f"{tag}_lds_roofline.json"), "w"), indent=1)
 print(json.dumps(lds, indent=1))
