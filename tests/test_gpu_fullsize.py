@@ -24,6 +24,17 @@ def _same(a, b):
     return np.array_equal(brute.sort_rows(a), brute.sort_rows(b))
 
 
+def _single_linkage_deaths(dm64):
+    """H0 deaths from scipy (neither our code nor ripser): single-linkage merge heights on the float32 distances,
+    zero heights dropped -- selected values, exact."""
+    from scipy.cluster.hierarchy import linkage
+    from scipy.spatial.distance import squareform
+    d = dm64.astype(np.float32).astype(np.float64)
+    np.fill_diagonal(d, 0.0)
+    h = np.sort(linkage(squareform(d, checks=False), method="single")[:, 2])
+    return h[h > 0]
+
+
 def _eeg_band_on_gpu(band, dev):
     g = torch.Generator(device=dev); g.manual_seed(1000 + band)
     A = torch.randn((N_REC, 1, 47, 8), generator=g, device=dev, dtype=torch.float64)
@@ -96,6 +107,11 @@ def test_config3_full_corpus_features(ctx):
             assert np.array_equal(od, ds[i])
             o = port.rips_dm(od)
             assert _same(h0s[i], o[0]) and _same(h1s[i, :c1s[i]], o[1])
+        # ---- and a larger sample of H0 against scipy's single linkage (an implementation that is not ours) ----
+        samp2 = torch.from_numpy(rng.choice(n, 400, replace=False)).to(dev)
+        d2 = dist[samp2].cpu().numpy(); h2 = dg.h0[samp2].cpu().numpy()
+        for i in range(len(d2)):
+            assert np.array_equal(h2[i, :46, 1], _single_linkage_deaths((d2[i] + d2[i].T) / 2.0))
         del X, dist, dg, dg2
     feats = feats.cpu().numpy()
     assert feats.shape == (1416, 220) and np.isfinite(feats).all()
@@ -123,6 +139,10 @@ def test_config4_audio_and_config5_pairs(ctx):
     for w in rng.choice(len(wins), 80, replace=False):
         (o0, o1), Pw = port.audio_persistence(wins[w], int(tau_h[w]))
         assert Pw == P[w] and _same(h0[w, :c0[w]], o0) and _same(h1[w, :c1[w]], o1), w
+    for w in rng.choice(len(wins), 300, replace=False):     # H0 against scipy's single linkage
+        pc = port.minmax_normalise(port.takens(wins[w], 3, int(tau_h[w]), 2))
+        ref = _single_linkage_deaths(port.cloud_dm(pc))
+        assert np.array_equal(h0[w, :c0[w] - 1, 1], ref) and np.isinf(h0[w, c0[w] - 1, 1]), w
     # ---- config 5: matched and mismatched pairs against 7,080 EEG diagrams ----
     g = torch.Generator(device=dev); g.manual_seed(7)
     n = len(wins)

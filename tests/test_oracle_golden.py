@@ -179,3 +179,42 @@ def test_wasserstein_port_vs_persim_restatement():
         A = np.sort(rng.random((int(rng.integers(1, 5)), 2)), axis=1)
         B = np.sort(rng.random((int(rng.integers(1, 5)), 2)), axis=1)
         assert abs(port.wasserstein(A, B) - brute.wasserstein_bruteforce(A, B)) < 1e-9
+
+
+def _single_linkage_deaths(dm64):
+    """H0 deaths by a library that is neither ours nor ripser: scipy's single-linkage merge heights on the float32
+    distances ripser would see (heights are selected distances, never computed: exact)."""
+    from scipy.cluster.hierarchy import linkage
+    from scipy.spatial.distance import squareform
+    d = dm64.astype(np.float32).astype(np.float64)
+    d = (d + d.T) / 2.0 if not np.array_equal(d, d.T) else d
+    np.fill_diagonal(d, 0.0)
+    return np.sort(linkage(squareform(d, checks=False), method="single")[:, 2])
+
+
+def test_h0_equals_scipy_single_linkage():
+    """H0 of a Vietoris-Rips filtration is single-linkage clustering: finite deaths = merge heights, zero heights
+    (coincident points) dropped, one essential class.  Pins the oracle's H0 -- float32 cast, threshold, zero rows,
+    row order -- against scipy on EEG-like matrices, white noise (near-tied lengths), and Takens clouds of all bands."""
+    from tda_eeg_audio_amd import synth
+    for kind in ("latent", "white"):
+        W = synth.eeg_windows(12, seed=31, kind=kind) if kind == "white" else synth.eeg_windows(12, seed=31)
+        for w in W:
+            _, d = port.corr_dist(w)
+            h0 = port.rips_dm(d)[0]
+            ref = _single_linkage_deaths((d + d.T) / 2.0)
+            ref = ref[ref > 0]
+            assert np.array_equal(h0[:-1, 1], ref) and np.all(h0[:, 0] == 0) and np.isinf(h0[-1, 1])
+    wins, _ = synth.audio_windows_all_bands(6, seed=5)
+    for w in wins:
+        tau = port.compute_tau(w, 125)
+        (h0, _), P = port.audio_persistence(w, tau)
+        pc = port.minmax_normalise(port.takens(w, 3, tau, 2))
+        ref = _single_linkage_deaths(port.cloud_dm(pc))
+        ref = ref[ref > 0]
+        assert len(pc) == P and np.array_equal(h0[:-1, 1], ref) and np.isinf(h0[-1, 1])
+    # coincident points: zero-height merges give no row
+    pts = np.array([[0.0, 0.0], [0.0, 0.0], [1.0, 0.0], [1.0, 0.0], [0.0, 2.0]])
+    dm = np.sqrt(((pts[:, None] - pts[None]) ** 2).sum(-1))
+    h0 = port.rips_dm(dm, thresh=10.0)[0]
+    assert np.array_equal(h0[:-1, 1], [1.0, 2.0]) and np.isinf(h0[-1, 1])
