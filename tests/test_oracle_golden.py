@@ -218,3 +218,57 @@ def test_h0_equals_scipy_single_linkage():
     dm = np.sqrt(((pts[:, None] - pts[None]) ** 2).sum(-1))
     h0 = port.rips_dm(dm, thresh=10.0)[0]
     assert np.array_equal(h0[:-1, 1], [1.0, 2.0]) and np.isinf(h0[-1, 1])
+
+
+def _polygon(n):
+    ang = 2.0 * np.pi * np.arange(n) / n
+    return np.stack([np.cos(ang), np.sin(ang)], axis=1)
+
+
+def polygon_h1(n):
+    """Vietoris-Rips of n evenly spaced points on the unit circle (Adamaszek & Adams, "The Vietoris-Rips complexes of
+    a circle", 2017): the complex with all chords of up to k steps is homotopy equivalent to a circle while k < n/3
+    and has no H1 from k >= n/3 on -- ONE class, born at the side 2 sin(pi/n), dying at the chord of ceil(n/3) steps."""
+    import math
+    return 2.0 * math.sin(math.pi / n), 2.0 * math.sin(math.pi * math.ceil(n / 3) / n)
+
+
+def test_h1_of_regular_polygons_matches_the_theorem():
+    """A known answer that is not ours for H1, with as many tied lengths as a metric can have (n chords per length):
+    every n from 4 to 60 gives exactly one H1 row at the theorem's values (float32 of the float64 chords), and
+    n - 1 finite H0 rows at the side length."""
+    for n in range(4, 61):
+        P = _polygon(n)
+        dm = np.sqrt(((P[:, None] - P[None]) ** 2).sum(-1))
+        h0, h1 = port.rips_dm(dm, thresh=10.0)
+        b, d = polygon_h1(n)
+        assert h1.shape == (1, 2), n
+        assert abs(h1[0, 0] - b) < 2e-7 * b and abs(h1[0, 1] - d) < 2e-7 * d, (n, h1, b, d)
+        assert len(h0) == n and np.all(np.abs(h0[:-1, 1] - b) < 2e-7 * b) and np.isinf(h0[-1, 1])
+        # under a threshold between birth and death the class is essential
+        h0t, h1t = port.rips_dm(dm, thresh=(b + d) / 2.0)
+        assert h1t.shape == (1, 2) and abs(h1t[0, 0] - b) < 2e-7 * b and np.isinf(h1t[0, 1]), n
+
+
+def lattice(k, dim=2):
+    import itertools
+    return np.array(list(itertools.product(range(k), repeat=dim)), dtype=np.float64)
+
+
+def test_h1_of_lattices_cube_and_cross_polytope():
+    """More answers that follow from the geometry alone: a k x k unit lattice has (k-1)^2 independent unit squares,
+    each filled when its diagonals arrive -- (k-1)^2 rows (1, sqrt 2), all alive at once (up to 100 classes); the
+    unit cube has 5 independent faces; the cross-polytope's edges all arrive at sqrt 2 together with the triangles
+    that fill them: no H1 row."""
+    def dm(P):
+        return np.sqrt(((P[:, None] - P[None]) ** 2).sum(-1))
+    r2 = np.float64(np.float32(np.sqrt(2.0)))
+    for k in range(2, 12):
+        h0, h1 = port.rips_dm(dm(lattice(k)), thresh=100.0)
+        assert h1.shape == ((k - 1) ** 2, 2) and np.all(h1[:, 0] == 1.0) and np.all(h1[:, 1] == r2), k
+        assert len(h0) == k * k and np.all(h0[:-1, 1] == 1.0)
+    h0, h1 = port.rips_dm(dm(lattice(2, 3)), thresh=100.0)
+    assert h1.shape == (5, 2) and np.all(h1[:, 0] == 1.0) and np.all(h1[:, 1] == r2)
+    for d in (3, 4, 5):
+        cross = np.concatenate([np.eye(d), -np.eye(d)])
+        assert len(port.rips_dm(dm(cross), thresh=100.0)[1]) == 0
