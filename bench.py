@@ -53,7 +53,7 @@ VALU_CLOCK_HZ = 2.4e9     # MI355X_MICROARCH.md: peak engine clock
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=40, help="timed passes (40 x 35 ms = 1.4 s at N = 1)")
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="corpus", choices=["corpus", "batch710"])
     ap.add_argument("--recordings", type=int, default=1416, help="recordings of the corpus (README.md:7)")
