@@ -9,7 +9,7 @@ Workload (default `--workload corpus`, BASELINE.json configs[2] + configs[4]): t
 dealt over the N ranks by whole recordings (dist.shard_recordings): STRONG scaling.  A step = ONE pass of the
 per-window hot path over the rank's share, resident in HBM (10 GB of float64 windows at N = 1, so nothing is served
 by the 256 MiB Infinity Cache), all five bands of the share as ONE batch per pass (`--per-band`: one batch per
-band), three passes in flight on their own streams as HIP graphs: per window corr->dist, Rips(EEG 47x47), tau per recording-band, Takens+Rips(audio,
+band), five passes in flight on their own streams as HIP graphs: per window corr->dist, Rips(EEG 47x47), tau per recording-band, Takens+Rips(audio,
 23..123 points over the five bands), Wasserstein H0 and H1, H1/H0 features, the per-recording reductions, and ONE
 all-gather of the (n_rec, 5 x 48) result rows per pass (RCCL over xGMI) inside the timed region -- what replaces
 run_analysis' serial loop (cmp:131-138) and the partial-file merge of scripts/tda_eeg_classification_v2.py:608-638.
@@ -64,10 +64,10 @@ def parse_args():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the features / PCIe legs")
     ap.add_argument("--no-graph", action="store_true", help="launch every step eagerly instead of replaying HIP graphs")
-    ap.add_argument("--lanes", type=int, default=int(os.environ.get("TDA_LANES", "0")),
-                    help="batches in flight (pipeline.Lanes); 0 = 3 with one batch per pass (2-5 lanes lie within 1 %% on "
-                         "the full corpus, 3 is best on an eighth of it), 5 with --per-band or --workload batch710 (one "
-                         "lane per band: the 710-window batches of configs[1] gain 14 %% over three lanes)")
+    ap.add_argument("--lanes", type=int, default=int(os.environ.get("TDA_LANES", "5")),
+                    help="batches in flight (pipeline.Lanes).  One batch per pass: 2-5 lanes lie within 1 %% on the full "
+                         "corpus, five are 1-2 %% ahead on the share a rank of four or eight holds; one batch per band "
+                         "(--per-band, --workload batch710): one lane per band, +14 %% over three on configs[1]")
     ap.add_argument("--class-words", default=os.environ.get("TDA_CLASS_WORDS", "1,1"),
                     help="first-pass class capacity (x64 bits for EEG, x32/x64 for audio); windows that need more are "
                          "redone by the widening passes inside the same step and counted in windows_repaired")
@@ -79,8 +79,6 @@ def parse_args():
                          "(exercises the N>1 code path on a one-GPU box; numbers are meaningless)")
     ap.add_argument("--cpu-worker", default=None, help=argparse.SUPPRESS)     # internal: the cpu_baseline child process
     args = ap.parse_args()
-    if args.lanes <= 0:
-        args.lanes = 5 if (args.per_band or args.workload == "batch710") else 3
     return args
 
 
