@@ -86,6 +86,8 @@ extern "C" __attribute__((visibility("default"))) int tda_profile_stop_after(int
     return hipMemcpyToSymbol(HIP_SYMBOL(g_stop_after), &n, sizeof(int)) != hipSuccess;
 }
 #define PROF_STOP(n, cleanup) do { if (g_stop_after == (n)) { cleanup; return; } } while (0)
+// inside the sweep: n + 100 * chunk stops after phase n of that chunk (11..19: phases, 20: end of the chunk)
+#define PROF_STOPC(n, cleanup) do { if (g_stop_after == (n) + 100 * prof_chunk) { cleanup; return; } } while (0)
 extern "C" __attribute__((visibility("default"))) int tda_profile_read(unsigned long long* out, int reset)
 {
     if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_prof), sizeof(unsigned long long) * 48) != hipSuccess) return 1;
@@ -102,6 +104,7 @@ extern "C" __attribute__((visibility("default"))) int tda_profile_read(unsigned 
 #define PROF_COUNT(i, v) do {} while (0)
 #define PROF_FLUSH() do {} while (0)
 #define PROF_STOP(n, cleanup) do {} while (0)
+#define PROF_STOPC(n, cleanup) do {} while (0)
 #endif
 
 #define WAVE_SYNC()                                            \
@@ -448,7 +451,7 @@ __device__ void rips_sweep(int n, int E, int Ev, const u16* rank, const u16* ord
     for (int i = tid; i < 256; i += NT) { adj[i] = 0ull; adjc[i] = 0ull; }
     if (tid == 0) {
         u32* lc = reinterpret_cast<u32*>(misc + MISC_MIN);     // list header: [0] entries, [1] earliest key
-        lc[0] = 0u; lc[1] = 0xffffffffu;
+        lc[0] = 0u; lc[1] = 0xffffffffu; lc[2] = 0u;               // [2]: whose turn it is in phase a
     }
     __syncthreads();
 
@@ -463,41 +466,59 @@ __device__ void rips_sweep(int n, int E, int Ev, const u16* rank, const u16* ord
     int ordcls = 0;                              // wave 0, one class word: lane i holds the i-th oldest class alive
     int cov_next = tid;                          // coverage check: first edge of this thread's residue class not yet seen covered
 #ifdef TDA_PROFILE
-    int prof_rneed = 0;
+    int prof_rneed = 0, prof_chunk = -1;
 #endif
     PROF_RESUME();
     for (int r0 = 0; r0 < Ev && !status; r0 += clen) {
         clen = NT;
         PROF_MARK(15);
+#ifdef TDA_PROFILE
+        ++prof_chunk;
+#endif
         PROF_COUNT(23, 1);
         const int r = r0 + tid;                      // (adjc was cleared at the end of the previous chunk)
         const bool valid = r < Ev;
         int a = 1, b = 0;
         if (valid) { const u32 pk = ord[r]; a = (int)(pk >> 8); b = (int)(pk & 255u); }     // ord[r] = (a << 8 | b), a > b
         const int tab = tri2(a) + b;
-        // adjacency rows of the chunk's own edges (whatever their position in the chunk)
-        if (valid) {
-            atomicOr(reinterpret_cast<unsigned long long*>(&adjc[2 * a + (b >> 6)]), 1ull << (b & 63));
-            atomicOr(reinterpret_cast<unsigned long long*>(&adjc[2 * b + (a >> 6)]), 1ull << (a & 63));
-        }
-        __syncthreads();
-        // ---- a. common-neighbour mask from the rank rows of a and b ----
+        // ---- a. common neighbours of (a,b) before edge r ----
+        // Neighbours through edges that predate the chunk come from the adjacency bit rows `adj`.  The chunk's own
+        // edges enter a second set of rows, `adjc`, WAVE BY WAVE in rank order: when wave w takes its turn, adjc holds
+        // exactly the chunk's edges of the waves before it -- all of them older than every edge of wave w -- so
+        // (adj | adjc)[a] & (adj | adjc)[b] is exact up to the 64 edges of the wave itself, and only vertices that
+        // become common through one of THOSE are confirmed against the rank table (about one per edge).  The waves
+        // hand the turn on through a word in LDS (the LDS serves the accesses of a wave in program order: rows read,
+        // own bits added, turn passed).  Before, all edges of the chunk entered adjc at once and every edge confirmed
+        // every vertex that the whole chunk had brought near it: 9 on average, 15-20 for the busiest lane of a wave,
+        // two rank lookups each -- a third of the vector instructions of the audio kernel.
         u64 M[NVW], M0[NVW];     // M: common neighbours before edge r; M0: those already common at chunk start
+        u64 Aj[NVW], Bj[NVW];
 #pragma unroll
-        for (int w = 0; w < NVW; ++w) { M[w] = 0; M0[w] = 0; }
-        // Common neighbours at chunk start come from the adjacency bit rows.  A vertex can only have become common
-        // since then through an edge of this chunk: those few candidates (bit rows of the chunk's edges) are
-        // confirmed against the rank table -- both edges older than r.  While no class is alive the exact mask only
-        // matters for edges that have no common neighbour yet (are they candidates?), so the confirmation of the
-        // others waits until a birth in this chunk makes it necessary (`lazy`).
-        bool lazy = true;
+        for (int w = 0; w < NVW; ++w) { M[w] = 0; M0[w] = 0; Aj[w] = 0; Bj[w] = 0; }
+        if (valid) {
 #pragma unroll
-        for (int c = 0; c < W; ++c) lazy = lazy && alive[c] == 0;
-        auto confirm = [&]() {
+            for (int w = 0; w < NVW; ++w) { Aj[w] = adj[2 * a + w]; Bj[w] = adj[2 * b + w]; M0[w] = Aj[w] & Bj[w]; }
+        }
+        {
+            volatile u32* turn = reinterpret_cast<volatile u32*>(misc + MISC_MIN) + 2;
+            if (wave > 0)
+                while (*turn < (u32)wave) __builtin_amdgcn_s_sleep(0);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            if (valid) {
+#pragma unroll
+                for (int w = 0; w < NVW; ++w) M[w] = (Aj[w] | adjc[2 * a + w]) & (Bj[w] | adjc[2 * b + w]);
+                atomicOr(reinterpret_cast<unsigned long long*>(&adjc[2 * a + (b >> 6)]), 1ull << (b & 63));
+                atomicOr(reinterpret_cast<unsigned long long*>(&adjc[2 * b + (a >> 6)]), 1ull << (a & 63));
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            if (lane == 0) *turn = (u32)wave + 1u;
+        }
+        if (valid) {
+            // through the wave's own edges (later waves may have added theirs meanwhile: the rank test rejects them)
             const int ta0 = tri2(a), tb0 = tri2(b);
 #pragma unroll
             for (int w = 0; w < NVW; ++w) {
-                u64 cc = (adj[2 * a + w] | adjc[2 * a + w]) & (adj[2 * b + w] | adjc[2 * b + w]) & ~M0[w];
+                u64 cc = (Aj[w] | adjc[2 * a + w]) & (Bj[w] | adjc[2 * b + w]) & ~M[w];
                 while (cc) {
                     const int v0 = 64 * w + __builtin_ctzll(cc); cc &= cc - 1ull;
                     const bool ok1 = cc != 0ull; const int v1 = ok1 ? 64 * w + __builtin_ctzll(cc) : v0; cc &= cc - 1ull;
@@ -508,21 +529,13 @@ __device__ void rips_sweep(int n, int E, int Ev, const u16* rank, const u16* ord
                     if (ok1 && (int)(xa1 > xb1 ? xa1 : xb1) < r) M[w] |= 1ull << (v1 & 63);
                 }
             }
-        };
-        bool deferred = false;                       // this lane's confirmation is still owed
-        if (valid) {
-            u64 any0 = 0ull;
-#pragma unroll
-            for (int w = 0; w < NVW; ++w) { M0[w] = adj[2 * a + w] & adj[2 * b + w]; M[w] = M0[w]; any0 |= M0[w]; }
-            if (lazy && any0) deferred = true;
-            else confirm();
         }
         u64 many = 0;
 #pragma unroll
         for (int w = 0; w < NVW; ++w) many |= M[w];
         const bool is_cand = valid && many == 0;
         PROF_MARK(4);
-        PROF_STOP(11, out_k0 = k0; out_k1 = k1; out_status = 0);
+        PROF_STOPC(11, out_k0 = k0; out_k1 = k1; out_status = 0);
         // ---- b. candidates (edges without a common neighbour): Kruskal in rank order ----
         // Only the union-find itself is sequential: wave 0 walks the candidates with the component labels
         // in registers and leaves one "merge" bit per edge.  Everything that follows from the decision
@@ -541,7 +554,7 @@ __device__ void rips_sweep(int n, int E, int Ev, const u16* rank, const u16* ord
         done[tid] = 0;
         __syncthreads();
         PROF_MARK(21);
-        PROF_STOP(12, out_k0 = k0; out_k1 = k1; out_status = 0);
+        PROF_STOPC(12, out_k0 = k0; out_k1 = k1; out_status = 0);
         int nfree = 0;
 #pragma unroll
         for (int c = 0; c < W; ++c) nfree += __builtin_popcountll((u64)(WT)~alive[c]);
@@ -718,7 +731,7 @@ __device__ void rips_sweep(int n, int E, int Ev, const u16* rank, const u16* ord
         }
         __syncthreads();
         PROF_MARK(22);
-        PROF_STOP(13, out_k0 = k0; out_k1 = k1; out_status = 0);
+        PROF_STOPC(13, out_k0 = k0; out_k1 = k1; out_status = 0);
         clen = offs[19];
         if (clen == 0) status |= TDA_WIN_CLASS_OVERFLOW;      // not even the first edge of the chunk fits
         if (clen < NT) PROF_COUNT(14, 1);
@@ -774,9 +787,8 @@ __device__ void rips_sweep(int n, int E, int Ev, const u16* rank, const u16* ord
         }
         }   // ncand > 0
         if (status) break;
-        if (deferred && btot > 0) confirm();         // a class was born after all: the chunk needs the exact masks
         PROF_MARK(5);
-        PROF_STOP(14, out_k0 = k0; out_k1 = k1; out_status = 0);
+        PROF_STOPC(14, out_k0 = k0; out_k1 = k1; out_status = 0);
         // No class alive and none born in this chunk: every psi entry is zero (dead classes were substituted out,
         // unwritten entries start at zero), so the apparent edges of the chunk get the zero vector they already hold
         // and no triangle can kill anything.  Phases c and d are skipped; only the adjacency rows move on.  This is
@@ -847,7 +859,7 @@ __device__ void rips_sweep(int n, int E, int Ev, const u16* rank, const u16* ord
         }
         __syncthreads();
         PROF_MARK(6);
-        PROF_STOP(15, out_k0 = k0; out_k1 = k1; out_status = 0);
+        PROF_STOPC(15, out_k0 = k0; out_k1 = k1; out_status = 0);
         // ---- d. the other triangles of every apparent edge ----
         // Link argument: if v and v' are common neighbours of (a,b) and adjacent to each other, the
         // tetrahedron (a,b,v,v') shows that triangles (a,b,v) and (a,b,v') carry the same boundary
@@ -915,7 +927,7 @@ __device__ void rips_sweep(int n, int E, int Ev, const u16* rank, const u16* ord
             if (NVW == 2) { m2 = (u32)rem[NVW - 1]; m3 = (u32)(rem[NVW - 1] >> 32); }
         }
         PROF_MARK(16);
-        PROF_STOP(16, out_k0 = k0; out_k1 = k1; out_status = 0);
+        PROF_STOPC(16, out_k0 = k0; out_k1 = k1; out_status = 0);
         // All non-trivial triangles of the chunk are listed under the frozen table (key = lane << 8 | v, the
         // order in which a sequential sweep meets them) and wave 0 reduces the list in registers: the
         // earliest non-zero vector kills the YOUNGEST class in it (elder rule) and is substituted into
@@ -1008,7 +1020,7 @@ __device__ void rips_sweep(int n, int E, int Ev, const u16* rank, const u16* ord
             }
             __syncthreads();
             PROF_MARK(17);
-            PROF_STOP(17, out_k0 = k0; out_k1 = k1; out_status = 0);
+            PROF_STOPC(17, out_k0 = k0; out_k1 = k1; out_status = 0);
             const u32 cnt = lcnt[0];
             if (cnt == 0u) break;
             const bool complete = cnt <= (u32)LCAP;
@@ -1263,7 +1275,7 @@ __device__ void rips_sweep(int n, int E, int Ev, const u16* rank, const u16* ord
             }
             __syncthreads();
             PROF_MARK(18);
-            PROF_STOP(18, out_k0 = k0; out_k1 = k1; out_status = 0);
+            PROF_STOPC(18, out_k0 = k0; out_k1 = k1; out_status = 0);
             WT kmask[W];
 #pragma unroll
             for (int c = 0; c < W; ++c) { const WT na = (WT)shared->alive[c]; kmask[c] = alive_before[c] & (WT)~na; alive[c] = na; }
@@ -1331,7 +1343,7 @@ __device__ void rips_sweep(int n, int E, int Ev, const u16* rank, const u16* ord
                 }
             }
             PROF_MARK(19);
-            PROF_STOP(19, out_k0 = k0; out_k1 = k1; out_status = 0);
+            PROF_STOPC(19, out_k0 = k0; out_k1 = k1; out_status = 0);
             if (complete && !more) break;
             if (++list_rounds > 4 * NT) { status |= TDA_WIN_CLASS_OVERFLOW; break; }   // every round kills >= 1 class: never reached
             __syncthreads();            // table rewritten before the chunk is listed again
@@ -1344,7 +1356,7 @@ __device__ void rips_sweep(int n, int E, int Ev, const u16* rank, const u16* ord
             atomicOr(reinterpret_cast<unsigned long long*>(&adj[2 * b + (a >> 6)]), 1ull << (a & 63));
         }
         if (tid < 256) adjc[tid] = 0ull;
-        if (tid == 0) { lcnt[0] = 0u; lcnt[1] = 0xffffffffu; shared->clen = 0x7fffffff; }
+        if (tid == 0) { lcnt[0] = 0u; lcnt[1] = 0xffffffffu; lcnt[2] = 0u; shared->clen = 0x7fffffff; }
         __syncthreads();
         // The end of the story: no class is alive and EVERY remaining edge already has a common neighbour, now and
         // (adjacency only grows) at its own time.  Then no remaining edge is a candidate: no component can merge,
@@ -1389,6 +1401,7 @@ __device__ void rips_sweep(int n, int E, int Ev, const u16* rank, const u16* ord
             }
         }
         PROF_MARK(7);
+        PROF_STOPC(20, out_k0 = k0; out_k1 = k1; out_status = 0);
     }
 #ifdef TDA_PROFILE
     PROF_COUNT(36, prof_rneed > 4096 ? 1 : 0); PROF_COUNT(37, prof_rneed > 4608 ? 1 : 0); PROF_COUNT(38, prof_rneed > 5120 ? 1 : 0);

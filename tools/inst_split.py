@@ -16,7 +16,13 @@ for band in ["beta", "delta"]:
     tau = engine.tau_batch(wins[:1].cpu().numpy(), 125, ctx=ctx)[0]
     tau_t = torch.full((NW,), int(tau), dtype=torch.int32, device=dev)
     out = engine.DeviceDiagrams(NW, 128, 256, dev)
-    for stop in (1, 2, 11, 12, 13, 14, 15, 16, 17, 18, 19, 0):
+    stops = [1, 2, 11, 12, 13, 14, 15, 16, 17, 18, 19, 0]
+    if os.environ.get("TDA_SPLIT_CHUNKS"):       # cumulative counts at the end of chunk 0..n-1, then everything
+        stops = [1, 2] + [20 + 100 * c for c in range(int(os.environ["TDA_SPLIT_CHUNKS"]))] + [0]
+    if os.environ.get("TDA_SPLIT_PHASES_OF"):    # the phases of chunk k (k >= 1), cumulative from the end of chunk k - 1
+        k = int(os.environ["TDA_SPLIT_PHASES_OF"])
+        stops = [20 + 100 * (k - 1)] + [n + 100 * k for n in range(11, 21)]
+    for stop in stops:
         lib.tda_profile_stop_after(stop)
         engine.takens_rips_dev(wins, tau_t, out, ctx=ctx); torch.cuda.synchronize()
 lib.tda_profile_stop_after(0)

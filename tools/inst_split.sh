@@ -13,6 +13,12 @@ for path in glob.glob(os.path.join(out, "pmc_split", "**", "*counter_collection.
         if "rips_cloud_kernel<512, 1, unsigned int, false" in r["Kernel_Name"]:
             rows[int(r["Dispatch_Id"])][r["Counter_Name"]] = float(r["Counter_Value"])
 stops = ["keys", "ranking", "a:mask", "b:cand-barrier", "b:walk", "b:publish", "c:deps", "d:closure", "d:list", "d:reduce", "d:table", "all"]
+if os.environ.get("TDA_SPLIT_PHASES_OF"):
+    k = int(os.environ["TDA_SPLIT_PHASES_OF"])
+    stops = [f"chunk {k - 1}", "a:mask", "b:cand-barrier", "b:walk", "b:publish", "c:deps", "d:closure", "d:list", "d:reduce", "d:table",
+             f"chunk {k} end"]
+elif os.environ.get("TDA_SPLIT_CHUNKS"):
+    stops = ["keys", "ranking"] + [f"chunk {c}" for c in range(int(os.environ["TDA_SPLIT_CHUNKS"]))] + ["all"]
 ids = sorted(rows)
 txt = []
 for bi, band in enumerate(["beta", "delta"]):
