@@ -107,6 +107,10 @@ extern "C" __attribute__((visibility("default"))) int tda_profile_read(unsigned 
 #define PROF_STOPC(n, cleanup) do {} while (0)
 #endif
 
+// Order between LDS accesses of ONE wave is kept by the hardware (the LDS serves a wave's instructions in issue order): a
+// flag written after data needs no s_waitcnt in between, only that the compiler keeps the two in program order.
+#define LDS_ORDER() asm volatile("" ::: "memory")
+
 #define WAVE_SYNC()                                            \
     do {                                                       \
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); \
@@ -510,7 +514,7 @@ __device__ void rips_sweep(int n, int E, int Ev, const u16* rank, const u16* ord
                 atomicOr(reinterpret_cast<unsigned long long*>(&adjc[2 * a + (b >> 6)]), 1ull << (b & 63));
                 atomicOr(reinterpret_cast<unsigned long long*>(&adjc[2 * b + (a >> 6)]), 1ull << (a & 63));
             }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            LDS_ORDER();
             if (lane == 0) *turn = (u32)wave + 1u;
         }
         if (valid) {
@@ -836,7 +840,7 @@ __device__ void rips_sweep(int n, int E, int Ev, const u16* rank, const u16* ord
         // until its own lanes are settled (a chain inside the wave advances one link per trip); the barrier after the
         // loop is the only one of the phase (it used to be two per dependency level: 12 to 29 levels per window).
         volatile unsigned char* vdone = done;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");       // (births and the lanes just above wrote their vectors)
+        LDS_ORDER();       // (births and the lanes just above wrote their vectors)
         if (!pending) vdone[tid] = 1;        // candidates, idle lanes and the lanes above are settled
 #ifdef TDA_PROFILE
         if (pending) atomicAdd(&prof_lds[33], 1ull);
@@ -851,7 +855,7 @@ __device__ void rips_sweep(int n, int E, int Ev, const u16* rank, const u16* ord
             if (ready) {
                 base = pxor(psi[d1], psi[d2]);
                 psi[tab] = base;
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                LDS_ORDER();
                 vdone[tid] = 1;
                 pending = false;
             }
