@@ -53,6 +53,9 @@
 #include "corr_dist_dev.h"
 #include <stdlib.h>
 
+#ifndef CLOUD_NB
+#define CLOUD_NB 8192          // ranking buckets of the point-cloud flavour
+#endif
 #define NT_MAX 512            // largest workgroup (point-cloud flavour); distance-matrix flavour uses 256
 #define RANK_NONE 0x7fffu
 
@@ -1718,7 +1721,7 @@ __device__ void rips_cloud_window(unsigned char* smem, const int win, const doub
     effective_threshold<NT>(P, tkey, vmax, kmin_thread, red, teff, kmin);
     PROF_MARK(0);
     PROF_STOP(1, if (tid == 0) { out.h0_cnt[win] = 0; out.h1_cnt[win] = 0; out.status[win] = 0; });
-    const int Ev = rank_edges<NT, 8192, false>(key32, E, teff, kmin, members, cursor, wsum, rank, ord, nullptr);
+    const int Ev = rank_edges<NT, CLOUD_NB, false>(key32, E, teff, kmin, members, cursor, wsum, rank, ord, nullptr);
     PROF_MARK(1);
     PROF_STOP(2, if (tid == 0) { out.h0_cnt[win] = 0; out.h1_cnt[win] = 0; out.status[win] = 0; });
     guard_write(smem, L);
@@ -1902,7 +1905,7 @@ static RipsLayout make_layout(int n, int psi_bytes_per_edge, int aux_bytes, int 
     L.off_aux = after_rank;
     L.off_misc = align16(L.off_aux + aux_bytes) + GUARD_BYTES;
     int misc_bytes = MISC_BYTES(8 * psi_bytes_per_edge);
-    const int nb = (NT == 256 && n <= 64) ? 2048 : 8192;
+    const int nb = (NT == 256 && n <= 64) ? 2048 : (NT == 512 ? CLOUD_NB : 8192);
     if (misc_bytes < MISC_SORTCNT + 2 * nb) misc_bytes = MISC_SORTCNT + 2 * nb;
     L.total = align16(L.off_misc + misc_bytes) + GUARD_BYTES;
     return L;
