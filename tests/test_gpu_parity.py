@@ -92,6 +92,45 @@ def test_h1_of_regular_polygons_matches_the_theorem(ctx):
         assert abs(c1[0][0, 0] - b) < 2e-7 * b and abs(c1[0][0, 1] - d) < 2e-7 * d, (n, c1[0])
 
 
+def test_h1_of_a_disjoint_union_is_the_union(ctx):
+    """Three regular polygons of different size far apart (39 points): three classes with three different births and
+    deaths alive together, each at its part's theorem values, through both kernels."""
+    from test_oracle_golden import far_polygons
+    pts, exp, _ = far_polygons()
+    dm = np.sqrt(((pts[:, None] - pts[None]) ** 2).sum(-1))
+    h0, h1, st = engine.rips_dm_batch(dm[None], thresh=100.0, ctx=ctx)
+    assert st[0] == 0 and h1[0].shape == (3, 2) and np.all(np.abs(h1[0] - exp) < 3e-7 * exp), h1[0]
+    c0, c1, st = engine.cloud_rips_batch(pts[None], normalise=False, thresh=100.0, ctx=ctx)
+    assert st[0] == 0 and c1[0].shape == (3, 2) and np.all(np.abs(c1[0] - exp) < 3e-7 * exp), c1[0]
+    assert np.array_equal(np.sort(c0[0][:, 1]), np.sort(h0[0][:, 1])) or np.allclose(np.sort(c0[0][:-1, 1]), np.sort(h0[0][:-1, 1]), rtol=3e-7)
+
+
+def test_scaling_by_a_power_of_two_scales_the_diagram_exactly(ctx):
+    """Properties that need no oracle: doubling or halving every distance (and the threshold) is exact in float32 and
+    float64, so every birth and death doubles or halves bit for bit and the row counts stay; a far-away extra point
+    adds one H0 merge at its distance and changes nothing else.  710 EEG-like matrices, 200 clouds."""
+    W = synth.eeg_windows(710, seed=77)
+    dist = engine.corr_dist_batch(W, want_corr=False, ctx=ctx)
+    h0, c0, h1, c1, st = engine.rips_dm_batch(dist, thresh=2.0, ctx=ctx, raw=True)
+    for f in (2.0, 0.5, 1024.0):
+        g0, d0, g1, d1, st2 = engine.rips_dm_batch(dist * f, thresh=2.0 * f, ctx=ctx, raw=True)
+        assert np.array_equal(d0, c0) and np.array_equal(d1, c1) and not st2.any()
+        for w in range(0, 710, 7):
+            assert np.array_equal(g0[w, :c0[w]], h0[w, :c0[w]] * f) and np.array_equal(g1[w, :c1[w]], h1[w, :c1[w]] * f)
+    rng = np.random.default_rng(5)
+    P = rng.random((200, 60, 3))
+    a0, a1, st = engine.cloud_rips_batch(P, normalise=False, thresh=100.0, ctx=ctx)
+    b0, b1, st2 = engine.cloud_rips_batch(P * 4.0, normalise=False, thresh=400.0, ctx=ctx)
+    assert not st.any() and not st2.any()
+    far = np.concatenate([P, np.full((200, 1, 3), 50.0)], axis=1)
+    f0, f1, st3 = engine.cloud_rips_batch(far, normalise=False, thresh=100.0, ctx=ctx)
+    assert not st3.any()
+    for w in range(200):
+        assert np.array_equal(b0[w], a0[w] * 4.0) and np.array_equal(b1[w], a1[w] * 4.0)
+        assert np.array_equal(f1[w], a1[w]) and len(f0[w]) == len(a0[w]) + 1
+        assert np.array_equal(f0[w][:len(a0[w]) - 1], a0[w][:-1]) and f0[w][-2, 1] > 40.0 and np.isinf(f0[w][-1, 1])
+
+
 def test_h1_of_lattices_cube_and_cross_polytope(ctx):
     """(k-1)^2 rows (1, sqrt 2) for the k x k unit lattice -- up to 81 classes alive at once, i.e. through the widening
     passes (100 classes on 121 points exceed what fits LDS: status bit 2) --, 5 for the unit cube, none for cross-polytopes (tests/test_oracle_golden.py has the argument); both

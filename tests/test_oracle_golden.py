@@ -272,3 +272,24 @@ def test_h1_of_lattices_cube_and_cross_polytope():
     for d in (3, 4, 5):
         cross = np.concatenate([np.eye(d), -np.eye(d)])
         assert len(port.rips_dm(dm(cross), thresh=100.0)[1]) == 0
+
+
+def far_polygons():
+    """Three regular polygons of different size far from each other (closer than the threshold, farther than any of
+    their deaths): the filtration below the gap is a disjoint union, so H1 is the three classes of the parts."""
+    parts = [(7, 1.0, (0.0, 0.0)), (12, 1.5, (10.0, 0.0)), (20, 0.8, (0.0, 10.0))]
+    pts = np.concatenate([r * _polygon(n) + np.array(c) for n, r, c in parts])
+    exp = sorted([(r * polygon_h1(n)[0], r * polygon_h1(n)[1]) for n, r, _ in parts], reverse=True)
+    return pts, np.array(exp), parts
+
+
+def test_h1_of_a_disjoint_union_is_the_union():
+    pts, exp, parts = far_polygons()
+    dm = np.sqrt(((pts[:, None] - pts[None]) ** 2).sum(-1))
+    h0, h1 = port.rips_dm(dm, thresh=100.0)
+    assert h1.shape == (3, 2) and np.all(np.abs(h1 - exp) < 3e-7 * exp), (h1, exp)     # rows come in descending birth
+    n_tot = len(pts)
+    sides = np.sort(np.concatenate([np.full(n - 1, np.float32(np.float32(r) * 0 + 2.0 * r * np.sin(np.pi / n))) for n, r, _ in parts]))
+    assert len(h0) == n_tot and np.isinf(h0[-1, 1])
+    assert np.all(np.abs(np.sort(h0[:n_tot - 3, 1]) - sides) < 3e-7 * sides)          # the sides of the three polygons
+    assert np.all(h0[n_tot - 3:n_tot - 1, 1] > 6.0)                                    # and the two gaps between them
