@@ -10,6 +10,21 @@
 
 typedef double d4 __attribute__((ext_vector_type(4)));
 
+// COMPILER FAULT (ROCm 7.2.0 hipcc, AMD clang 22, gfx950), proven in round 3 -- why no kernel that calls this may be
+// built with its MFMA accumulators in AGPRs (launch bound of ONE wave per SIMD).  The result of
+// v_mfma_f64_16x16x4_f64 may be read 18 wait states after issue at the earliest, and on gfx950 that is the software's
+// business (no interlock).  With the accumulators in AGPRs the hazard recogniser emits, on the path where a wave has
+// no second block in a tile (the conditional q = 1 of mfma_tile),
+//       v_mfma_f64_16x16x4_f64 a[0:7], ...; s_and_b64; s_cbranch_vccnz; s_waitcnt lgkmcnt(0);
+//       s_nop 0; v_accvgpr_read_b32 v19, a7; s_nop 11; v_accvgpr_read_b32 v18, a6; ...
+// i.e. a7 -- the high half of accumulator element 3 -- is read FOUR states after the MFMA and keeps the value of one
+// k-step earlier.  Measured (tools/probes/wide_waves_repro.py on a -DTDA_EEG_WIDE_WAVES=1 build): every distance that
+// involves a channel with (ch & 15) >> 2 == 3 is off by up to 4e-2, everything else is exact; with `s_nop 15; s_nop 3`
+// patched into the assembly in front of that one read (tools/probes/patch_mfma_hazard.sh) the same build is bit-exact.
+// Only the streaming (RES = false) widening variants show the pattern (3 places in rips.hip's code object, none with
+// VGPR accumulators); a wait spelled out in the source does not help, because the compiler places the AGPR copies in
+// front of it.  tests/test_capi_and_host.py::test_mfma_kernels_keep_accumulators_in_vgprs pins NumAgprs == 0.
+
 
 // global -> registers (issued early, consumed after the current tile has been used).  Element
 // idx = tid + 256 k of a tile is (channel idx / 64, sample idx % 64): a wave reads 512 contiguous bytes.
@@ -110,7 +125,7 @@ __device__ __forceinline__ void cd_window_products(unsigned char* smem, const do
                 sacc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[1][0], 1.0, sacc, 0, 0, 0);
                 sacc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[1][1], 1.0, sacc, 0, 0, 0);
             }
-        }
+            }
     };
     if constexpr (RES) {
 #pragma unroll

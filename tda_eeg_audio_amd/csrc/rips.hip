@@ -56,6 +56,18 @@
 #ifndef CLOUD_NB
 #define CLOUD_NB 8192          // ranking buckets of the point-cloud flavour
 #endif
+#ifndef NARROW_NT
+#define NARROW_NT 512          // workgroup of the narrow first pass (384 works too: measured slower)
+#endif
+#ifndef NARROW_WAVES
+#define NARROW_WAVES 6         // launch bound, waves per SIMD: three workgroups of 512 per CU = 24 waves = 80 VGPRs
+#endif
+#if defined(TDA_PROFILE) && !defined(TDA_PROFILE_STOPS_ONLY)
+#define NARROW_NB (NARROW_NT == 384 ? 1536 : 1024)   // (the phase counters take 384 bytes of LDS: fewer buckets in this build)
+#else
+#define NARROW_NB (NARROW_NT == 384 ? 1536 : 2048)   // ... and its ranking buckets (a multiple of 2 NT that fits)
+#endif
+#define NARROW_EMAX 7626       // ... and the edges it is built for: 124 points (a Takens cloud of a 250-sample window, tau = 1)
 #define NT_MAX 512            // largest workgroup (point-cloud flavour); distance-matrix flavour uses 256
 #define RANK_NONE 0x7fffu
 
@@ -64,6 +76,15 @@
 // Per-workgroup sums live in LDS (thread 0 adds, no atomics) and are flushed to the global table once per
 // window: hundreds of workgroups hammering the same global counters at every mark cost more than the phases.
 __device__ unsigned long long g_prof[48];
+#ifdef TDA_PROFILE_STOPS_ONLY
+// (make PROFILE=1 EXTRA=-DTDA_PROFILE_STOPS_ONLY: only the stop points, for exact instruction counts per phase under
+// rocprofv3 -- no timers, no static LDS, so the layouts and the residency are the product's)
+#define PROF_BEGIN() do {} while (0)
+#define PROF_RESUME() do {} while (0)
+#define PROF_MARK(i) do {} while (0)
+#define PROF_COUNT(i, v) do {} while (0)
+#define PROF_FLUSH() do {} while (0)
+#else
 __shared__ unsigned long long prof_lds[48];
 #define PROF_BEGIN()                                                       \
     if (threadIdx.x < 48) prof_lds[threadIdx.x] = 0ull;                    \
@@ -82,6 +103,7 @@ __shared__ unsigned long long prof_lds[48];
         __syncthreads();                                                   \
         if (threadIdx.x < 48 && prof_lds[threadIdx.x]) atomicAdd(&g_prof[threadIdx.x], prof_lds[threadIdx.x]); \
     } while (0)
+#endif
 // experiment knob of the diagnostic build: the Rips kernels return after phase n (1: keys, 2: ranking); 0 = run all
 __device__ int g_stop_after;
 extern "C" __attribute__((visibility("default"))) int tda_profile_stop_after(int n)
@@ -114,6 +136,7 @@ extern "C" __attribute__((visibility("default"))) int tda_profile_read(unsigned 
 // flag written after data needs no s_waitcnt in between, only that the compiler keeps the two in program order.
 #define LDS_ORDER() asm volatile("" ::: "memory")
 
+#define LAUNDER(v) asm volatile("" : "+v"(v))
 #define WAVE_SYNC()                                            \
     do {                                                       \
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); \
@@ -197,7 +220,7 @@ struct WgVote {
 template <int NT>
 __device__ __forceinline__ bool wg_any(WgVote& v, bool p)
 {
-    static_assert(NT == 256 || NT == 512, "slots are read as one or two 16-byte words");
+    static_assert(NT % 64 == 0 && NT <= 512, "slots are read as one or two 16-byte words; slots beyond NT / 64 hold zero");
     const bool w = __ballot(p) != 0ull;
     u32* s = v.slots + 8 * v.parity;
     if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = w ? 1u : 0u;
@@ -205,7 +228,7 @@ __device__ __forceinline__ bool wg_any(WgVote& v, bool p)
     v.parity ^= 1;
     const uint4 x = *reinterpret_cast<const uint4*>(s);
     u32 r = x.x | x.y | x.z | x.w;
-    if (NT == 512) { const uint4 y = *reinterpret_cast<const uint4*>(s + 4); r |= y.x | y.y | y.z | y.w; }
+    if (NT > 256) { const uint4 y = *reinterpret_cast<const uint4*>(s + 4); r |= y.x | y.y | y.z | y.w; }
     return r != 0u;
 }
 template <int NT>
@@ -338,7 +361,7 @@ __device__ int rank_edges(const u32* key32, int E, u32 teff, u32 kmin, u16* memb
     __syncthreads();
     // ---- rank ----
     const u16* cur16 = reinterpret_cast<const u16*>(cursor);
-    const int Ev = (int)cur16[NB - 1];                // end of the last bucket = edges within the effective threshold
+    const int Ev = uni((int)cur16[NB - 1]);           // end of the last bucket = edges within the effective threshold
 #pragma unroll 4
     for (int e = tid; e < E; e += NT) {
         const u32 b = rank[e];
@@ -371,6 +394,159 @@ __device__ int rank_edges(const u32* key32, int E, u32 teff, u32 kmin, u16* memb
     return Ev;
 }
 
+// ---------------------------------------------------------------------------------
+// The narrow first pass of the point-cloud kernel: one third of a CU's LDS per workgroup, and a layout that is FIXED at
+// compile time (sized for 124 points in up to three dimensions, whatever the clouds of the batch): every LDS address of
+// the sweep is then a lane-dependent index plus an immediate offset of the ds instruction.  With the offsets as kernel
+// arguments the compiler kept two dozen loop-invariant addresses in registers across the sweep and, at the 80 VGPRs
+// that three 512-thread workgroups per CU leave, spilled them to scratch: the reloads sat in the single-wave
+// stretches of every chunk.
+//   ranking:  [keys 4E][members 2E][cursors 2 NB][scratch]                          ...     [points]
+//   sweep:    [rank 2E][class vectors by rank ->   (one region, NL::REGION bytes)   <- ord][misc][points]
+// ---------------------------------------------------------------------------------
+#if defined(TDA_PROFILE) && !defined(TDA_PROFILE_STOPS_ONLY)
+#define NARROW_LDS ((160 * 1024 / 3 / 1280) * 1280 - 384)     // (the phase counters take 384 bytes of static LDS)
+#else
+// LDS is handed out in granules of 1,280 bytes on gfx950 (160 KB / 128): a third of a CU is 42 granules = 53,760 bytes
+// (54,608 = 163,840 / 3 rounded down to 16 is rounded UP to 43 granules by the hardware and only two workgroups fit:
+// measured, the kernel ran at the residency of the wide layout)
+#define NARROW_LDS ((160 * 1024 / 3 / 1280) * 1280)
+#endif
+#define NARROW_PMAX 124
+#define NARROW_DIM 3
+#ifdef TDA_DEBUG_PTS
+#define NL_GUARD 16
+#else
+#define NL_GUARD 0
+#endif
+#define NL_A16(x) (((x) + 15) & ~15)
+struct NL {                                              // byte offsets of the narrow layout
+    static constexpr int E = NARROW_EMAX;
+    static constexpr int RANK = 0;
+    static constexpr int PSI = NL_A16(2 * E) + NL_GUARD;
+    static constexpr int MEMBERS = NL_A16(4 * E);
+    static constexpr int CURSOR = NL_A16(MEMBERS + 2 * E);
+    static constexpr int RSCR = CURSOR + 2 * NARROW_NB;  // vmax, min-max scratch, wave sums, reductions: 720 bytes
+    static constexpr int TOTAL = NARROW_LDS;
+    static constexpr int AUX = TOTAL - NL_GUARD - NL_A16(NARROW_PMAX * NARROW_DIM * 8);
+    static constexpr int MISC = AUX - NL_GUARD - NL_A16(8752 + 8 * 32);      // MISC_BYTES(32), checked on the host side
+    static constexpr int REGION = MISC - NL_GUARD - PSI;  // class vectors from its start, ord at its end
+    static_assert(RSCR + 720 <= AUX - NL_GUARD, "the ranking arrays must end in front of the points");
+    static_assert(REGION >= 2 * E + 8 * 512, "the first chunks must fit: class vectors of 2 NT ranks next to the whole of ord");
+};
+
+// ---------------------------------------------------------------------------------
+// The same ranking for the NARROW first pass of the point-cloud kernel (three workgroups per CU: 54.6 KB of LDS per
+// window instead of 79): no bucket index parked in the rank table (recomputed for the scatter), 2,048 buckets instead
+// of 8,192 -- and the rank table
+// takes the place of the keys: every thread keeps the ranks of its (at most 16) edges in eight registers across the
+// barrier that ends the last read of a key, and `ord` is written from them at the end of the region it shares with
+// the class vectors (see rips_sweep).  LDS during the ranking: keys 4E | members 2E | cursors 2 NB.
+// The walk over a bucket (3.6 members on average now) fetches four members per trip: two LDS round trips per four
+// members instead of two per member.
+// ---------------------------------------------------------------------------------
+template <int NT, int NB>
+__device__ __forceinline__ int rank_edges_narrow(const u32* key32, int E, u32 teff, u32 kmin, u16* members, u32* cursor, int* wsum,
+                                                 u16* rank, u16* ord)
+{
+    static_assert(NB % (2 * NT) == 0, "every thread scans whole words");
+    static_assert(NB <= 0x8000, "bucket indices are parked in 16 bits, 0xffff = beyond the threshold");
+    constexpr int WPT = NB / NT / 2;                  // packed words per thread in the scan
+    constexpr int EPT = 2 * ((NARROW_EMAX + 2 * NT - 1) / (2 * NT));      // edges per thread, at most (even)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    Bucketer bk;
+    bk.dmin = sortable_f32(kmin);
+    bk.top = (float)(NB - 1);
+    bk.scale = bk.top / (sortable_f32(teff) - bk.dmin);
+    for (int i = tid; i < NB / 2; i += NT) cursor[i] = 0u;
+    __syncthreads();
+    // ---- count; the bucket of every edge stays in a register (two per VGPR) until its rank takes the place ----
+    u32 rk[EPT / 2];
+#pragma unroll
+    for (int i = 0; i < EPT; ++i) {
+        const int e = tid + i * NT;
+        u32 b = 0xffffu;
+        if (e < E) {
+            const u32 k = key32[e];
+            if (k <= teff) { b = (u32)bk(k); atomicAdd(&cursor[b >> 1], 1u << (16 * (b & 1))); }
+        }
+        if (i & 1) rk[i >> 1] |= b << 16; else rk[i >> 1] = b;
+    }
+    __syncthreads();
+    // ---- scan ----
+    {
+        u32 w[WPT];
+        int s = 0;
+#pragma unroll
+        for (int i = 0; i < WPT; ++i) {
+            const u32 x = cursor[tid * WPT + i];
+            const int c0 = (int)(x & 0xffffu), c1 = (int)(x >> 16);
+            w[i] = (u32)s | ((u32)(s + c0) << 16);    // exclusive prefix inside the thread
+            s += c0 + c1;
+        }
+        const int incl = wave_incl_scan_i32(s);
+        if (lane == 63) wsum[wave] = incl;
+        __syncthreads();
+        int basep = incl - s;
+        for (int q = 0; q < wave; ++q) basep += wsum[q];
+        const u32 add = (u32)basep * 0x00010001u;     // both halves (sums stay below 65,536)
+#pragma unroll
+        for (int i = 0; i < WPT; ++i) cursor[tid * WPT + i] = w[i] + add;
+    }
+    __syncthreads();
+    // ---- scatter: afterwards cursor[b] = end of bucket b = start of bucket b + 1 ----
+#pragma unroll
+    for (int i = 0; i < EPT; ++i) {
+        const u32 b = i & 1 ? rk[i >> 1] >> 16 : rk[i >> 1] & 0xffffu;
+        if (b != 0xffffu) {
+            const int sh = 16 * (int)(b & 1u);
+            const u32 old = atomicAdd(&cursor[b >> 1], 1u << sh);
+            members[(old >> sh) & 0xffffu] = (u16)(tid + i * NT);
+        }
+    }
+    __syncthreads();
+    // ---- rank: rank(e) = start of its bucket + the members that precede it in (key, flat index) order.  Four members
+    // per trip; (key, index) pairs are compared as 64-bit numbers; the slots beyond the end of the bucket hold the
+    // edge itself, which does not precede itself ----
+    const u16* cur16 = reinterpret_cast<const u16*>(cursor);
+    const int Ev = uni((int)cur16[NB - 1]);           // end of the last bucket = edges within the effective threshold
+#pragma unroll
+    for (int i = 0; i < EPT; ++i) {
+        const u32 e = (u32)(tid + i * NT);
+        const u32 b = i & 1 ? rk[i >> 1] >> 16 : rk[i >> 1] & 0xffffu;
+        u32 r = RANK_NONE;
+        if (b != 0xffffu) {
+            const u32 k = key32[e];
+            const u64 me = ((u64)k << 32) | e;
+            const int lo = b ? (int)cur16[b - 1] : 0, hi = (int)cur16[b];
+            int c = 0;
+            for (int j = lo; j < hi; j += 4) {
+                u32 m[4], km[4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) m[t] = j + t < hi ? (u32)members[j + t] : e;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) km[t] = key32[m[t]];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) c += ((((u64)km[t] << 32) | m[t]) < me) ? 1 : 0;
+            }
+            r = (u32)(lo + c);
+        }
+        if (i & 1) rk[i >> 1] = (rk[i >> 1] & 0xffffu) | (r << 16); else rk[i >> 1] = (rk[i >> 1] & 0xffff0000u) | r;
+    }
+    __syncthreads();                                  // rank and ord lie over the keys / members: every read of those is done
+#pragma unroll
+    for (int i = 0; i < EPT; ++i) {
+        const int e = tid + i * NT;
+        if (e < E) {
+            const u32 r = i & 1 ? rk[i >> 1] >> 16 : rk[i >> 1] & 0xffffu;
+            rank[e] = (u16)r;
+            if (r != RANK_NONE) { const int a = edge_row(e); ord[r] = (u16)((a << 8) | (e - tri2(a))); }
+        }
+    }
+    __syncthreads();
+    return Ev;
+}
+
 struct RipsOut {
     double* h0; int h0_cap; int* h0_cnt;
     double* h1; int h1_cap; int* h1_cnt;
@@ -381,6 +557,9 @@ struct RipsLayout {
     int off_members;                            // ranking phase: keys at 0, then the bucket members
     int off_rank, off_ord, off_aux, off_misc;   // sweep phase: psi at 0, rank, ord; then aux and misc
     int total;
+    // narrow layout (make_narrow_layout): rank at 0, class vectors by rank behind it, `ord` = the chunk table
+    int off_psi, psi_cap, off_cursor, off_rscr;
+    int guard[5], n_guard;                      // guard build: where the sentinels end (regions that start there)
 };
 
 // Guard build (make DEBUG_PTS=1): 16 sentinel bytes in front of rank, ord, aux and misc and at the end of the
@@ -395,20 +574,36 @@ struct RipsLayout {
 #define TDA_SOLO_BEGIN() __builtin_amdgcn_s_setprio(TDA_SOLO_PRIO)
 #define TDA_SOLO_END() __builtin_amdgcn_s_setprio(0)
 
+// Every poll on an LDS word gives up after this many idle trips (a trip is an LDS round trip plus a sleep: >= 150
+// cycles, so >= 10 M cycles; the longest legitimate wait -- seven hand-overs, or a dependency chain of ~30 links, on a
+// fully loaded CU -- stays below 1,000 trips).  A wave that gives up raises the workgroup's poison word, lets the
+// others through and the window ends with TDA_WIN_NOT_CONVERGED: a defect in a dependency table becomes a status
+// bit, never a hang.
+#define TDA_POLL_LIMIT (1 << 16)
+#ifdef TDA_DEBUG_PTS
+// guard build only: tda_debug_inject(1) makes wave 3 keep the turn of phase a to itself, (2) makes one apparent edge
+// of every chunk wait for itself -- tests/test_gpu_stress.py expects status 8 back, not a hang
+__device__ int g_fault;
+extern "C" __attribute__((visibility("default"))) int tda_debug_inject(int what)
+{
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_fault), &what, sizeof(int)) != hipSuccess;
+}
+#define TDA_FAULT(n) (g_fault == (n))
+#else
+#define TDA_FAULT(n) false
+#endif
 #ifdef TDA_DEBUG_PTS
 #define GUARD_BYTES 16
 __device__ __forceinline__ void guard_write(unsigned char* smem, const RipsLayout& L)
 {
-    const int offs[5] = {L.off_rank, L.off_ord, L.off_aux, L.off_misc, L.total};
-    if (threadIdx.x < 20) reinterpret_cast<u32*>(smem + offs[threadIdx.x >> 2] - GUARD_BYTES)[threadIdx.x & 3] = 0xC0FFEE00u + threadIdx.x;
+    if ((int)threadIdx.x < 4 * L.n_guard) reinterpret_cast<u32*>(smem + L.guard[threadIdx.x >> 2] - GUARD_BYTES)[threadIdx.x & 3] = 0xC0FFEE00u + threadIdx.x;
     __syncthreads();
 }
 __device__ __forceinline__ int guard_check(unsigned char* smem, const RipsLayout& L)
 {
     __syncthreads();
-    const int offs[5] = {L.off_rank, L.off_ord, L.off_aux, L.off_misc, L.total};
     bool bad = false;
-    if (threadIdx.x < 20) bad = reinterpret_cast<u32*>(smem + offs[threadIdx.x >> 2] - GUARD_BYTES)[threadIdx.x & 3] != 0xC0FFEE00u + threadIdx.x;
+    if ((int)threadIdx.x < 4 * L.n_guard) bad = reinterpret_cast<u32*>(smem + L.guard[threadIdx.x >> 2] - GUARD_BYTES)[threadIdx.x & 3] != 0xC0FFEE00u + threadIdx.x;
     return __syncthreads_or(bad ? 1 : 0) ? TDA_WIN_LDS_GUARD : 0;
 }
 #else
@@ -437,13 +632,33 @@ __device__ __forceinline__ int guard_check(unsigned char*, const RipsLayout&) { 
 // The sweep (phase P3).  KEYFN(r, a, b) returns the float32 length of sorted edge r = (a,b).
 // All control flow is workgroup-uniform; ord/rank/psi/misc live in LDS.
 // ---------------------------------------------------------------------------------
-template <int NT, int NVW, int W, typename WT, class KEYFN>
-__device__ void rips_sweep(int n, int E, int Ev, const u16* rank, const u16* ord, Psi<W, WT>* psi,
+// NARROW (the first pass of the point-cloud kernel at three workgroups per CU): the class vectors are indexed by RANK
+// and share ONE region of LDS with `ord`:
+//   * psi[r] belongs to the edge of rank r and grows upwards from the start of the region, 4 bytes per rank; ord[r]
+//     lies at the END of the region, 2 bytes per rank (ord[E - 1] in its last two bytes).  A chunk [r0, r0 + NT) reads
+//     ord from r0 on only (its own edges, the end-of-story walk) and class vectors below r0 + NT only, so the two never
+//     meet as long as 4 (r0 + NT) <= region - 2 (E - r0): for a 124-point cloud classes may stay alive up to rank
+//     ~5,500 of 7,626 (they live to ~2,000 on average, beyond 5,100 in 0.6 % of the windows).  A busy chunk beyond
+//     that flags the window TDA_WIN_CLASS_OVERFLOW for the wide pass, like a window that runs out of class bits;
+//     quiet chunks need no class vectors and go on;
+//   * a triangle side (flat index j) is psi[rank[j]] -- one more dependent LDS read in the triangle list, none in
+//     phase c (the ranks of the two reference edges are needed there anyway); the rewrite after a kill walks the
+//     vectors directly, without `ord`;
+//   * every chunk clears the vectors of its own ranks first (the region held `ord` entries of dead ranks there).
+// (forced inline: left to itself the compiler outlined one instantiation of the point-cloud kernel, and an outlined
+// sweep gets its LDS pointers as generic 64-bit ones -- flat loads instead of ds_read, every phase 20-40 % slower)
+template <int NT, int NVW, int W, typename WT, bool NARROW, class KEYFN>
+__device__ __forceinline__ void rips_sweep(int n, int E, int Ev, const u16* rank, const u16* ord, Psi<W, WT>* psi, int psi_bytes,
                            unsigned char* misc, KEYFN keyfn, double* h0, int h0_cap, double* h1, int h1_cap,
                            int& out_k0, int& out_k1, int& out_status)
 {
-    const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
+    static_assert(!NARROW || W == 1, "the narrow layout is the point-cloud first pass");
+    int psi_cap = 0;                                 // NARROW: set per chunk
+    // The thread index is handed to every chunk through an opaque move (LAUNDER): scaled copies of it (tid * 4, lane * 8,
+    // ...: the indices of two dozen LDS arrays) are then recomputed per chunk where they are used instead of being hoisted
+    // out of the chunk loop and kept -- or, at 80 VGPRs, spilled to scratch and reloaded in the single-wave stretches.
+    const int tid0 = threadIdx.x;
+    const int lane0 = tid0 & 63, wave = uni(tid0 >> 6);
     int* brank = reinterpret_cast<int*>(misc + MISC_BRANK);
     u64* cand = reinterpret_cast<u64*>(misc + MISC_CAND);
     unsigned char* done = misc + MISC_DONE;
@@ -453,12 +668,18 @@ __device__ void rips_sweep(int n, int E, int Ev, const u16* rank, const u16* ord
     float* bkey = reinterpret_cast<float*>(misc + MISC_BRANK + 4 * WB * W);
     u64* adjc = reinterpret_cast<u64*>(misc + MISC_ADJC);    // adjc[2*v + w]: neighbours of v through edges of this chunk
 
-    for (int e = tid; e < E; e += NT) psi[e] = pzero<W, WT>();
-    for (int i = tid; i < WB * W; i += NT) { brank[i] = -1; bkey[i] = 0.f; }
-    for (int i = tid; i < 256; i += NT) { adj[i] = 0ull; adjc[i] = 0ull; }
-    if (tid == 0) {
+    if constexpr (!NARROW) for (int e = tid0; e < E; e += NT) psi[e] = pzero<W, WT>();
+    for (int i = tid0; i < WB * W; i += NT) { brank[i] = -1; bkey[i] = 0.f; }
+    for (int i = tid0; i < 256; i += NT) { adj[i] = 0ull; adjc[i] = 0ull; }
+    if (tid0 == 0) {
         u32* lc = reinterpret_cast<u32*>(misc + MISC_MIN);     // list header: [0] entries, [1] earliest key
         lc[0] = 0u; lc[1] = 0xffffffffu; lc[2] = 0u;               // [2]: whose turn it is in phase a
+        lc[3] = 0u;                                                // [3]: poison (a poll gave up: TDA_POLL_LIMIT)
+        shared->status = 0;
+    }
+    if (tid0 < 16) {                                                // vote slots and ballots of waves that do not exist (NT = 384)
+        reinterpret_cast<u32*>(misc + MISC_WV)[tid0] = 0u;
+        cand[tid0] = 0ull;
     }
     __syncthreads();
 
@@ -467,16 +688,19 @@ __device__ void rips_sweep(int n, int E, int Ev, const u16* rank, const u16* ord
 #pragma unroll
     for (int c = 0; c < W; ++c) alive[c] = 0;
     int k0 = 0, k1 = 0, merges = 0, status = 0;
-    int compA = lane, compB = lane + 64;     // component labels of vertices lane / lane+64 (used by wave 0)
+    int compA = lane0, compB = lane0 + 64;     // component labels of vertices lane0 / lane0+64 (used by wave 0)
 
     int clen = NT;
-    int ordcls = 0;                              // wave 0, one class word: lane i holds the i-th oldest class alive
-    int cov_next = tid;                          // coverage check: first edge of this thread's residue class not yet seen covered
+    int ordcls = 0;                              // wave 0, one class word: lane0 i holds the i-th oldest class alive
+    int cov_next = tid0;                          // coverage check: first edge of this thread's residue class not yet seen covered
 #ifdef TDA_PROFILE
     int prof_rneed = 0, prof_chunk = -1;
 #endif
     PROF_RESUME();
     for (int r0 = 0; r0 < Ev && !status; r0 += clen) {
+        int tid = tid0;
+        LAUNDER(tid);
+        const int lane = tid & 63;
         clen = NT;
         PROF_MARK(15);
 #ifdef TDA_PROFILE
@@ -488,6 +712,12 @@ __device__ void rips_sweep(int n, int E, int Ev, const u16* rank, const u16* ord
         int a = 1, b = 0;
         if (valid) { const u32 pk = ord[r]; a = (int)(pk >> 8); b = (int)(pk & 255u); }     // ord[r] = (a << 8 | b), a > b
         const int tab = tri2(a) + b;
+        const int slot = NARROW ? r : tab;               // where the class vector of this edge lives
+        // NARROW: psi_cap = the ranks whose vectors lie clear of ord[r0 ...] in this chunk (psi and ord share a region)
+        if constexpr (NARROW) {
+            psi_cap = (psi_bytes - 2 * (E - r0)) >> 2;
+            if (r < psi_cap) psi[r] = pzero<W, WT>();
+        }
         // ---- a. common neighbours of (a,b) before edge r ----
         // Neighbours through edges that predate the chunk come from the adjacency bit rows `adj`.  The chunk's own
         // edges enter a second set of rows, `adjc`, WAVE BY WAVE in rank order: when wave w takes its turn, adjc holds
@@ -508,8 +738,13 @@ __device__ void rips_sweep(int n, int E, int Ev, const u16* rank, const u16* ord
         }
         {
             volatile u32* turn = reinterpret_cast<volatile u32*>(misc + MISC_MIN) + 2;
-            if (wave > 0)
-                while (*turn < (u32)wave) __builtin_amdgcn_s_sleep(0);
+            if (wave > 0) {
+                int trips = 0;
+                while (*turn < (u32)wave) {
+                    if (++trips > TDA_POLL_LIMIT) { if (lane == 0) turn[1] = 1u; break; }     // poison: see TDA_POLL_LIMIT
+                    __builtin_amdgcn_s_sleep(0);
+                }
+            }
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
             if (valid) {
 #pragma unroll
@@ -518,7 +753,7 @@ __device__ void rips_sweep(int n, int E, int Ev, const u16* rank, const u16* ord
                 atomicOr(reinterpret_cast<unsigned long long*>(&adjc[2 * b + (a >> 6)]), 1ull << (a & 63));
             }
             LDS_ORDER();
-            if (lane == 0) *turn = (u32)wave + 1u;
+            if (lane == 0 && !(TDA_FAULT(1) && wave == 3)) *turn = (u32)wave + 1u;
         }
         if (valid) {
             // through the wave's own edges (later waves may have added theirs meanwhile: the rank test rejects them)
@@ -541,6 +776,28 @@ __device__ void rips_sweep(int n, int E, int Ev, const u16* rank, const u16* ord
 #pragma unroll
         for (int w = 0; w < NVW; ++w) many |= M[w];
         const bool is_cand = valid && many == 0;
+        // apex of the triangle that kills an apparent edge at once (phase c): ANY common neighbour is valid (the other
+        // triangles are verified in phase d); prefer one whose two edges predate the chunk, so that psi[a,v*] and
+        // psi[b,v*] are final already and no in-chunk dependency arises.  Chosen here, with the ranks of its two edges,
+        // while the masks are at hand: the two look-ups overlap the other waves' turns, and M0 dies here
+        int vstar = 0, d1 = 0, d2 = 0, q1 = 0, q2 = 0;
+        {
+            u64 many0 = 0;
+#pragma unroll
+            for (int w = 0; w < NVW; ++w) many0 |= M0[w];
+            if (many0) {
+                if (NVW == 1 || M0[0]) vstar = __builtin_ctzll(M0[0]);
+                else vstar = 64 + __builtin_ctzll(M0[NVW - 1]);
+            } else if (many) {
+                if (NVW == 1 || M[0]) vstar = __builtin_ctzll(M[0]);
+                else vstar = 64 + __builtin_ctzll(M[NVW - 1]);
+            }
+            if (valid && many != 0) {
+                d1 = pair_index(a, vstar); d2 = pair_index(b, vstar);
+                q1 = (int)rank[d1] - r0; q2 = (int)rank[d2] - r0;   // < tid
+                if (TDA_FAULT(2) && tid == 77 && q1 >= 0) q1 = tid;
+            }
+        }
         PROF_MARK(4);
         PROF_STOPC(11, out_k0 = k0; out_k1 = k1; out_status = 0);
         // ---- b. candidates (edges without a common neighbour): Kruskal in rank order ----
@@ -665,7 +922,7 @@ __device__ void rips_sweep(int n, int E, int Ev, const u16* rank, const u16* ord
             // The walk stops at the first birth that finds no free class bit: the chunk is closed just before
             // that edge, so that the kills of the shortened chunk can free bits (capacity = classes alive at
             // once).  q = NT: the whole chunk went through.
-            const u64 candv = cand[lane & (NT / 64 - 1)];     // all ballots in one LDS read
+            const u64 candv = cand[lane & 7];                 // all ballots in one LDS read
             int q = par ? qpar : NT, births = 0;
             const bool walk = !par;
             for (int g = 0; g < NT / 64 && walk; ++g) {
@@ -739,7 +996,7 @@ __device__ void rips_sweep(int n, int E, int Ev, const u16* rank, const u16* ord
         __syncthreads();
         PROF_MARK(22);
         PROF_STOPC(13, out_k0 = k0; out_k1 = k1; out_status = 0);
-        clen = offs[19];
+        clen = uni(offs[19]);                                 // (workgroup-uniform values read from LDS: to SGPRs)
         if (clen == 0) status |= TDA_WIN_CLASS_OVERFLOW;      // not even the first edge of the chunk fits
         if (clen < NT) PROF_COUNT(14, 1);
         bool mrg = is_cand && ((mbal[wave] >> lane) & 1ull);
@@ -748,8 +1005,8 @@ __device__ void rips_sweep(int n, int E, int Ev, const u16* rank, const u16* ord
         const u64 below = (1ull << lane) - 1ull;
         const int bpre = offs[wave] + __builtin_popcountll(__ballot(birth) & below);
         const int rpre = offs[8 + wave] + __builtin_popcountll(__ballot(row) & below);
-        btot = offs[16];
-        const int rtot = offs[17], mtot = offs[18];
+        btot = uni(offs[16]);
+        const int rtot = uni(offs[17]), mtot = uni(offs[18]);
         if (!status) {
             if (row) {
                 const int pos = k0 + rpre;
@@ -763,7 +1020,7 @@ __device__ void rips_sweep(int n, int E, int Ev, const u16* rank, const u16* ord
 #pragma unroll
                 for (int c = 0; c < W; ++c)
                     if (c == cw) nv.w[c] = ((WT)1 << bit);
-                psi[tab] = nv;
+                if (!NARROW || r < psi_cap) psi[slot] = nv;
                 brank[idx] = r;
                 bkey[idx] = mykey;
             }
@@ -808,33 +1065,21 @@ __device__ void rips_sweep(int n, int E, int Ev, const u16* rank, const u16* ord
 #ifdef TDA_PROFILE
         if (!quiet) prof_rneed = r0 + clen;          // class vectors are needed for the ranks below this
 #endif
+        if constexpr (NARROW) {
+            // a busy chunk whose class vectors would reach into ord[r0 ...]: for the wide pass
+            if (!quiet && r0 + NT > psi_cap) { status |= TDA_WIN_CLASS_OVERFLOW; break; }
+        }
         if (!quiet) {
         // ---- c. apparent edges: psi[e] = psi[a,v*] ^ psi[b,v*] ----
-        // apex of the triangle that kills the edge at once: ANY common neighbour is valid (the other
-        // triangles are verified below); prefer one whose two edges predate the chunk, so that
-        // psi[a,v*] and psi[b,v*] are final already and no in-chunk dependency arises
-        u64 many0 = 0;
-#pragma unroll
-        for (int w = 0; w < NVW; ++w) many0 |= M0[w];
-        int vstar = 0;
-        if (many0) {
-            if (NVW == 1 || M0[0]) vstar = __builtin_ctzll(M0[0]);
-            else vstar = 64 + __builtin_ctzll(M0[NVW - 1]);
-        } else if (many) {
-            if (NVW == 1 || M[0]) vstar = __builtin_ctzll(M[0]);
-            else vstar = 64 + __builtin_ctzll(M[NVW - 1]);
-        }
+        // (the apex v* and the ranks of its two edges were found in phase a)
         const bool apparent = valid && many != 0 && tid < clen;
-        int d1 = 0, d2 = 0, q1 = 0, q2 = 0;
-        if (apparent) {
-            d1 = pair_index(a, vstar); d2 = pair_index(b, vstar);
-            q1 = (int)rank[d1] - r0; q2 = (int)rank[d2] - r0;   // < tid
-        }
         bool pending = apparent;
         Psi<W, WT> base = pzero<W, WT>();
+        // (NARROW: the vector of an edge is found at its rank, which is what q1 / q2 hold)
+        const int s1 = NARROW ? q1 + r0 : d1, s2 = NARROW ? q2 + r0 : d2;
         if (apparent && q1 < 0 && q2 < 0) {  // both edges predate the chunk (see v*): final already, no waiting
-            base = pxor(psi[d1], psi[d2]);
-            psi[tab] = base;
+            base = pxor(psi[s1], psi[s2]);
+            psi[slot] = base;
             pending = false;
         }
         // The rest waits for its two edges, WITHOUT barriers: dependencies point at earlier edges of the chunk only,
@@ -846,9 +1091,12 @@ __device__ void rips_sweep(int n, int E, int Ev, const u16* rank, const u16* ord
         LDS_ORDER();       // (births and the lanes just above wrote their vectors)
         if (!pending) vdone[tid] = 1;        // candidates, idle lanes and the lanes above are settled
 #ifdef TDA_PROFILE
+#ifndef TDA_PROFILE_STOPS_ONLY
         if (pending) atomicAdd(&prof_lds[33], 1ull);
+#endif
         PROF_COUNT(34, 1);
 #endif
+        int idle_trips = 0;
         while (__ballot(pending)) {
             PROF_COUNT(32, 1);
             bool ready = false;
@@ -856,13 +1104,20 @@ __device__ void rips_sweep(int n, int E, int Ev, const u16* rank, const u16* ord
             const u64 rbal = __ballot(ready);
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
             if (ready) {
-                base = pxor(psi[d1], psi[d2]);
-                psi[tab] = base;
+                base = pxor(psi[s1], psi[s2]);
+                psi[slot] = base;
                 LDS_ORDER();
                 vdone[tid] = 1;
                 pending = false;
             }
-            if (!rbal) __builtin_amdgcn_s_sleep(1);                  // nothing to do this trip: leave the issue slots to the others (0 / 1 / 2 / 4: no difference measured)
+            if (!rbal) {
+                if (++idle_trips > TDA_POLL_LIMIT) {                 // give up: poison, and let the waiters on MY lanes through
+                    if (lane == 0) reinterpret_cast<volatile u32*>(misc + MISC_MIN)[3] = 1u;
+                    if (pending) vdone[tid] = 1;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(1);                         // nothing to do this trip: leave the issue slots to the others (0 / 1 / 2 / 4: no difference measured)
+            }
         }
         __syncthreads();
         PROF_MARK(6);
@@ -950,7 +1205,8 @@ __device__ void rips_sweep(int n, int E, int Ev, const u16* rank, const u16* ord
         // trailing zeros instead of a reduction over the wave.  Entries of ONE edge may come in any order: the
         // classes they kill and the images of those classes depend on their span only.
         constexpr bool SORTED = W == 1;
-        constexpr int HIST_BYTES = SORTED ? NT + 8 : 0;              // u8 hist[NT] behind the entries (8-byte aligned)
+        constexpr int HISTN = (NT + 255) & ~255;                     // (counters beyond NT stay zero: the scan reads whole words)
+        constexpr int HIST_BYTES = SORTED ? HISTN + 8 : 0;           // u8 hist[NT] behind the entries (8-byte aligned)
         constexpr int LMAX = SORTED ? 255 : 256;                     // (sorted: offsets are bytes)
         constexpr int LCAP = ((MISC_LIST_BYTES - HIST_BYTES) / ES) < LMAX ? ((MISC_LIST_BYTES - HIST_BYTES) / ES) : LMAX;
         constexpr int LPL = (LCAP + 63) / 64;
@@ -963,9 +1219,11 @@ __device__ void rips_sweep(int n, int E, int Ev, const u16* rank, const u16* ord
 #ifdef TDA_PROFILE
         {   // diagnostic: triangles left to test after the link closure, and apparent edges
             const int ntri = __builtin_popcount(m0) + __builtin_popcount(m1) + __builtin_popcount(m2) + __builtin_popcount(m3);
+#ifndef TDA_PROFILE_STOPS_ONLY
             if (ntri) atomicAdd(&prof_lds[27], (unsigned long long)ntri);
             if (apparent) atomicAdd(&prof_lds[28], 1ull);
             if (ntri) atomicAdd(&prof_lds[29], 1ull);
+#endif
         }
 #endif
         int list_rounds = 0;
@@ -978,7 +1236,7 @@ __device__ void rips_sweep(int n, int E, int Ev, const u16* rank, const u16* ord
             Psi<W, WT> firsty = pzero<W, WT>();
             u32 mycnt = 0u;                                          // entries of this thread in this round
             if (apparent) {
-                base = psi[tab];
+                base = psi[slot];
                 Psi<W, WT> prev = pzero<W, WT>();                    // a repeated vector reduces to zero: skip it
                 // (64 vertices per word: the four triangles of a trip may come from anywhere in it)
 #pragma unroll
@@ -992,8 +1250,10 @@ __device__ void rips_sweep(int n, int E, int Ev, const u16* rank, const u16* ord
                         const bool ok3 = mm != 0ull; const int v3 = ok3 ? vbase + __builtin_ctzll(mm) : v0; mm &= mm - 1ull;
 #define TDA_IDX_(v, ja, jb)                                                       \
                         const int t##ja = (int)(__umul24((u32)(v), (u32)((v) - 1)) >> 1); \
-                        const int ja = (v) < a ? ta_ + (v) : t##ja + a;                    \
-                        const int jb = (v) < b ? tb_ + (v) : t##ja + b;
+                        const int f##ja = (v) < a ? ta_ + (v) : t##ja + a;                 \
+                        const int f##jb = (v) < b ? tb_ + (v) : t##ja + b;                 \
+                        const int ja = NARROW ? (int)rank[f##ja] : f##ja;                  \
+                        const int jb = NARROW ? (int)rank[f##jb] : f##jb;
                         TDA_IDX_(v0, ja0, jb0) TDA_IDX_(v1, ja1, jb1) TDA_IDX_(v2, ja2, jb2) TDA_IDX_(v3, ja3, jb3)
 #undef TDA_IDX_
                         const Psi<W, WT> p0 = psi[ja0], q0 = psi[jb0], p1 = psi[ja1], q1_ = psi[jb1];
@@ -1020,7 +1280,10 @@ __device__ void rips_sweep(int n, int E, int Ev, const u16* rank, const u16* ord
                     }
                 }
             }
-            if (SORTED) hist[tid] = (unsigned char)mycnt;
+            if (SORTED) {
+                hist[tid] = (unsigned char)mycnt;
+                if (NT < HISTN && tid < HISTN - NT) hist[NT + tid] = 0;
+            }
             {
                 const u32 wmin = wave_min_u32_dpp(firstkey);
                 if (lane == 0 && wmin != 0xffffffffu) atomicMin(&lcnt[1], wmin);
@@ -1028,7 +1291,7 @@ __device__ void rips_sweep(int n, int E, int Ev, const u16* rank, const u16* ord
             __syncthreads();
             PROF_MARK(17);
             PROF_STOPC(17, out_k0 = k0; out_k1 = k1; out_status = 0);
-            const u32 cnt = lcnt[0];
+            const u32 cnt = (u32)uni((int)lcnt[0]);
             if (cnt == 0u) break;
             const bool complete = cnt <= (u32)LCAP;
             PROF_COUNT(11, 1);
@@ -1064,7 +1327,7 @@ __device__ void rips_sweep(int n, int E, int Ev, const u16* rank, const u16* ord
                 if (SORTED && complete) {
                     // exclusive prefix over hist[] (HW packed words of four counts per lane; at most 255 entries, so
                     // bytes never carry), entries written back at offset-of-thread + index-in-thread, reloaded
-                    constexpr int HW = NT / 256;
+                    constexpr int HW = HISTN / 256;
                     u32* hw = reinterpret_cast<u32*>(hist) + HW * lane;
                     const u32 x0 = hw[0], x1 = HW == 2 ? hw[HW - 1] : 0u;
                     const u32 s0 = __builtin_amdgcn_sad_u8(x0, 0u, 0u);
@@ -1285,11 +1548,14 @@ __device__ void rips_sweep(int n, int E, int Ev, const u16* rank, const u16* ord
             PROF_STOPC(18, out_k0 = k0; out_k1 = k1; out_status = 0);
             WT kmask[W];
 #pragma unroll
-            for (int c = 0; c < W; ++c) { const WT na = (WT)shared->alive[c]; kmask[c] = alive_before[c] & (WT)~na; alive[c] = na; }
-            k1 = shared->k1;
-            const int nk = shared->nk;
-            const bool more = shared->more != 0;
-            status = shared->status;
+            for (int c = 0; c < W; ++c) {
+                const WT na = sizeof(WT) == 8 ? (WT)uni64(shared->alive[c]) : (WT)uni((int)(u32)shared->alive[c]);
+                kmask[c] = alive_before[c] & (WT)~na; alive[c] = na;
+            }
+            k1 = uni(shared->k1);
+            const int nk = uni(shared->nk);
+            const bool more = uni(shared->more) != 0;
+            status = uni(shared->status);
             if (status) break;
             if (FTAB) {
                 // ---- rewrite: p -> (p minus killed classes) ^ images of the killed classes it contained ----
@@ -1298,7 +1564,7 @@ __device__ void rips_sweep(int n, int E, int Ev, const u16* rank, const u16* ord
                 const int seen_end = r0 + clen < Ev ? r0 + clen : Ev;          // the last chunk may be short
 #pragma unroll 4
                 for (int rr = tid; rr < seen_end; rr += NT) {
-                    const int e = edge_flat(ord[rr]);
+                    const int e = NARROW ? rr : edge_flat(ord[rr]);
                     const Psi<W, WT> p = psi[e];
                     WT anyh = 0;
 #pragma unroll
@@ -1332,7 +1598,7 @@ __device__ void rips_sweep(int n, int E, int Ev, const u16* rank, const u16* ord
                     }
 #pragma unroll 4
                     for (int rr = tid; rr < (r0 + clen < Ev ? r0 + clen : Ev); rr += NT) {
-                        const int e = edge_flat(ord[rr]);
+                        const int e = NARROW ? rr : edge_flat(ord[rr]);
                         Psi<W, WT> p = psi[e];
                         bool changed = false;
 #pragma unroll
@@ -1363,18 +1629,22 @@ __device__ void rips_sweep(int n, int E, int Ev, const u16* rank, const u16* ord
             atomicOr(reinterpret_cast<unsigned long long*>(&adj[2 * b + (a >> 6)]), 1ull << (a & 63));
         }
         if (tid < 256) adjc[tid] = 0ull;
-        if (tid == 0) { lcnt[0] = 0u; lcnt[1] = 0xffffffffu; lcnt[2] = 0u; shared->clen = 0x7fffffff; }
+        if (tid == 0) {
+            lcnt[0] = 0u; lcnt[1] = 0xffffffffu; lcnt[2] = 0u; shared->clen = 0x7fffffff;
+            if (lcnt[3]) shared->status = TDA_WIN_NOT_CONVERGED;          // (sampled by ONE thread: the verdict is uniform)
+        }
         __syncthreads();
+        if (uni(shared->status) & TDA_WIN_NOT_CONVERGED) { status |= TDA_WIN_NOT_CONVERGED; break; }
         // The end of the story: no class is alive and EVERY remaining edge already has a common neighbour, now and
         // (adjacency only grows) at its own time.  Then no remaining edge is a candidate: no component can merge,
         // no class can be born, and with nothing alive nothing can die -- the rest of the filtration adds no row.
         if (quiet) {
+            const int from = r0 + clen;
+            bool covered = true;
             // every thread walks its own residue class of the remaining edges and remembers where it stopped: an edge
             // that is covered stays covered, so no edge is looked at twice over all the checks of a window
-            const int from = r0 + clen;
-            int rr = from + ((tid - from) & (NT - 1));
+            int rr = (NT & (NT - 1)) == 0 ? from + ((tid - from) & (NT - 1)) : from + (((tid - from) % NT) + NT) % NT;
             rr = rr > cov_next ? rr : cov_next;
-            bool covered = true;
             while (rr < Ev) {
                 const u32 pk = ord[rr];
                 const int ea = (int)(pk >> 8), eb = (int)(pk & 255u);
@@ -1391,7 +1661,7 @@ __device__ void rips_sweep(int n, int E, int Ev, const u16* rank, const u16* ord
                 if (lane == 0 && wmin != 0x7fffffffu) atomicMin(reinterpret_cast<unsigned int*>(&shared->clen), wmin);
             }
             __syncthreads();
-            const int ru = shared->clen;
+            const int ru = uni(shared->clen);
             if (ru >= Ev) { PROF_COUNT(25, 1); PROF_MARK(7); break; }
             // ... so the edges up to it only join the adjacency rows, and the next chunk starts AT it: whole chunks of
             // the long-edge tail that hold no candidate are never swept
@@ -1401,6 +1671,8 @@ __device__ void rips_sweep(int n, int E, int Ev, const u16* rank, const u16* ord
                     const int ea = (int)(pk >> 8), eb = (int)(pk & 255u);
                     atomicOr(reinterpret_cast<unsigned long long*>(&adj[2 * ea + (eb >> 6)]), 1ull << (eb & 63));
                     atomicOr(reinterpret_cast<unsigned long long*>(&adj[2 * eb + (ea >> 6)]), 1ull << (ea & 63));
+                    // NARROW: no chunk will clear the vectors of the edges that are skipped (ord[r2] is read: dead now)
+                    if constexpr (NARROW) { if (r2 < ((psi_bytes - 2 * (E - ru)) >> 2)) psi[r2] = pzero<W, WT>(); }
                 }
                 PROF_COUNT(35, ru - from);
                 clen = ru - r0;                                  // (the loop advances r0 by clen)
@@ -1417,7 +1689,7 @@ __device__ void rips_sweep(int n, int E, int Ev, const u16* rank, const u16* ord
     // essential classes
     const int ncomp = n - merges;
     for (int i = 0; i < ncomp; ++i) {
-        if (k0 < h0_cap && tid == 0) { h0[2 * k0] = 0.0; h0[2 * k0 + 1] = (double)INFINITY; }
+        if (k0 < h0_cap && tid0 == 0) { h0[2 * k0] = 0.0; h0[2 * k0 + 1] = (double)INFINITY; }
         ++k0;
     }
 #pragma unroll
@@ -1426,7 +1698,7 @@ __device__ void rips_sweep(int n, int E, int Ev, const u16* rank, const u16* ord
         while (al) {
             const int bit = __builtin_ctzll(al);
             al &= al - 1;
-            if (k1 < h1_cap && tid == 0) { h1[2 * k1] = (double)bkey[WB * c + bit]; h1[2 * k1 + 1] = (double)INFINITY; }
+            if (k1 < h1_cap && tid0 == 0) { h1[2 * k1] = (double)bkey[WB * c + bit]; h1[2 * k1 + 1] = (double)INFINITY; }
             ++k1;
         }
     }
@@ -1470,7 +1742,7 @@ __device__ void rips_dm_rest(unsigned char* smem, const int win, int n, float th
     guard_write(smem, L);
     int k0, k1, st;
     KeyFromLds kf{skey};
-    rips_sweep<NT, NVW, W, WT>(n, E, Ev, rank, ord, psi, misc, kf,
+    rips_sweep<NT, NVW, W, WT, false>(n, E, Ev, rank, ord, psi, 0, misc, kf,
                        out.h0 + (size_t)win * out.h0_cap * 2, out.h0_cap,
                        out.h1 + (size_t)win * out.h1_cap * 2, out.h1_cap, k0, k1, st);
     st |= guard_check(smem, L);
@@ -1604,7 +1876,7 @@ __device__ __noinline__ void row_maxima(const u32* key32, u32* vmax, int P)
 // 64 and 128 classes: four waves per SIMD (128 VGPRs, no spills).  Five (96 VGPRs, 32 B of scratch per lane) paid while
 // the sweep spent its time at barriers; with the one-barrier votes four is 1 % faster end to end
 template <int NT, int NVW, int W, typename WT, bool RETRY>
-__global__ void __launch_bounds__(NT, (W <= 2 && !RETRY) ? 4 : 2)      // (never 1: see eeg_window_kernel)
+__global__ void __launch_bounds__(NT, (W <= 2 && !RETRY) ? 4 : 2)
 rips_dm_kernel(const double* __restrict__ dm, int n_win, int n, float thresh, int symmetrise, RipsLayout L,
                RipsOut out, unsigned long long* __restrict__ retry_ctr)
 {
@@ -1620,7 +1892,7 @@ rips_dm_kernel(const double* __restrict__ dm, int n_win, int n, float thresh, in
     }
 }
 
-template <int NT, int W, typename WT>
+template <int NT, int W, typename WT, bool NARROW>
 __device__ void rips_cloud_window(unsigned char* smem, const int win, const double* __restrict__ src,
                                   const int* __restrict__ tau_or_npts, int n_t_or_pcap, int dim, int subsample,
                                   int mode, int normalise, float thresh, const RipsLayout& L, int p_max,
@@ -1628,14 +1900,16 @@ __device__ void rips_cloud_window(unsigned char* smem, const int win, const doub
 {
     const int tid = threadIdx.x;
     u32* key32 = reinterpret_cast<u32*>(smem);
-    u16* members = reinterpret_cast<u16*>(smem + L.off_members);
-    Psi<W, WT>* psi = reinterpret_cast<Psi<W, WT>*>(smem);
-    u16* rank = reinterpret_cast<u16*>(smem + L.off_rank);
-    u16* ord = reinterpret_cast<u16*>(smem + L.off_ord);
-    double* pts = reinterpret_cast<double*>(smem + L.off_aux);
-    unsigned char* misc = smem + L.off_misc;
-    u32* red = reinterpret_cast<u32*>(misc + MISC_MIN);
-    double* mm = reinterpret_cast<double*>(misc + MISC_CKEY);    // min/max scratch (before the sweep)
+    u16* members = reinterpret_cast<u16*>(smem + (NARROW ? NL::MEMBERS : L.off_members));
+    Psi<W, WT>* psi = reinterpret_cast<Psi<W, WT>*>(smem + (NARROW ? NL::PSI : 0));
+    u16* rank = reinterpret_cast<u16*>(smem + (NARROW ? NL::RANK : L.off_rank));
+    u16* ord = reinterpret_cast<u16*>(smem + L.off_ord);         // NARROW: at the end of the region of the class vectors (below)
+    double* pts = reinterpret_cast<double*>(smem + (NARROW ? NL::AUX : L.off_aux));
+    unsigned char* misc = smem + (NARROW ? NL::MISC : L.off_misc);
+    // scratch of the phases before the sweep: the head of `misc`; the narrow layout keeps it clear of the ranking arrays
+    unsigned char* rscr = smem + (NARROW ? NL::RSCR : L.off_misc);
+    u32* red = reinterpret_cast<u32*>(rscr + MISC_MIN);
+    double* mm = reinterpret_cast<double*>(rscr + (NARROW ? MISC_CAND : MISC_CKEY));    // min/max scratch
 
     double* h0 = out.h0 + (size_t)win * out.h0_cap * 2;
     double* h1 = out.h1 + (size_t)win * out.h1_cap * 2;
@@ -1701,9 +1975,9 @@ __device__ void rips_cloud_window(unsigned char* smem, const int win, const doub
     const int E = tri2(P);
     const u32 tkey = f32_sortable(thresh);
     KeyFromPts kf{pts, dim};
-    u32* vmax = reinterpret_cast<u32*>(misc + MISC_COMP);
-    u32* cursor = reinterpret_cast<u32*>(misc + MISC_SORTCNT);
-    int* wsum = reinterpret_cast<int*>(misc + MISC_WV);
+    u32* vmax = reinterpret_cast<u32*>(rscr + MISC_COMP);
+    u32* cursor = reinterpret_cast<u32*>(smem + (NARROW ? NL::CURSOR : L.off_cursor));
+    int* wsum = reinterpret_cast<int*>(rscr + MISC_WV);
     if (tid < 128) vmax[tid] = 0u;
     __syncthreads();
     u32 kmin_thread = 0xffffffffu;
@@ -1721,15 +1995,20 @@ __device__ void rips_cloud_window(unsigned char* smem, const int win, const doub
     effective_threshold<NT>(P, tkey, vmax, kmin_thread, red, teff, kmin);
     PROF_MARK(0);
     PROF_STOP(1, if (tid == 0) { out.h0_cnt[win] = 0; out.h1_cnt[win] = 0; out.status[win] = 0; });
-    const int Ev = rank_edges<NT, CLOUD_NB, false>(key32, E, teff, kmin, members, cursor, wsum, rank, ord, nullptr);
+    int Ev;
+    if constexpr (NARROW) {
+        ord = reinterpret_cast<u16*>(smem + NL::PSI + NL::REGION) - E;        // ord[E - 1] ends the region
+        Ev = rank_edges_narrow<NT, NARROW_NB>(key32, E, teff, kmin, members, cursor, wsum, rank, ord);
+    }
+    else Ev = rank_edges<NT, CLOUD_NB, false>(key32, E, teff, kmin, members, cursor, wsum, rank, ord, nullptr);
     PROF_MARK(1);
     PROF_STOP(2, if (tid == 0) { out.h0_cnt[win] = 0; out.h1_cnt[win] = 0; out.status[win] = 0; });
     guard_write(smem, L);
     int k0, k1, st;
     if (P <= 64)
-        rips_sweep<NT, 1, W, WT>(P, E, Ev, rank, ord, psi, misc, kf, h0, out.h0_cap, h1, out.h1_cap, k0, k1, st);
+        rips_sweep<NT, 1, W, WT, NARROW>(P, E, Ev, rank, ord, psi, NL::REGION, misc, kf, h0, out.h0_cap, h1, out.h1_cap, k0, k1, st);
     else
-        rips_sweep<NT, 2, W, WT>(P, E, Ev, rank, ord, psi, misc, kf, h0, out.h0_cap, h1, out.h1_cap, k0, k1, st);
+        rips_sweep<NT, 2, W, WT, NARROW>(P, E, Ev, rank, ord, psi, NL::REGION, misc, kf, h0, out.h0_cap, h1, out.h1_cap, k0, k1, st);
     st |= guard_check(smem, L);
     PROF_MARK(3);
     PROF_COUNT(8, 1);
@@ -1746,8 +2025,11 @@ __device__ void rips_cloud_window(unsigned char* smem, const int win, const doub
 #ifndef CLOUD_WAVES
 #define CLOUD_WAVES 4
 #endif
-template <int NT, int W, typename WT, bool RETRY>
-__global__ void __launch_bounds__(NT, RETRY ? 2 : CLOUD_WAVES)
+// NARROW: three workgroups of 384 threads per CU = 18 waves, five per SIMD at most: 96 VGPRs.  (Three workgroups of 512
+// would need six waves per SIMD: at 80 VGPRs the sweep spills the thread index and half of its scalars, and every
+// phase, the single-wave stretches included, ran 20-40 % longer -- measured: more than the third workgroup brought.)
+template <int NT, int W, typename WT, bool RETRY, bool NARROW = false>
+__global__ void __launch_bounds__(NT, RETRY ? 2 : (NARROW ? NARROW_WAVES : CLOUD_WAVES))
 rips_cloud_kernel(const double* __restrict__ src, const int* __restrict__ tau_or_npts, int n_win,
                   int n_t_or_pcap, int dim, int subsample, int mode, int normalise, float thresh,
                   RipsLayout L, int p_max, int* __restrict__ n_points, RipsOut out,
@@ -1762,13 +2044,13 @@ rips_cloud_kernel(const double* __restrict__ src, const int* __restrict__ tau_or
         atomicExch(&span[0], wall_clock64());
     if constexpr (!RETRY) {                               // one window per workgroup, no loop (see eeg_window_kernel)
         if ((int)blockIdx.x < n_win)
-            rips_cloud_window<NT, W, WT>(smem, (int)blockIdx.x, src, tau_or_npts, n_t_or_pcap, dim, subsample, mode,
-                                         normalise, thresh, L, p_max, n_points, out);
+            rips_cloud_window<NT, W, WT, NARROW>(smem, (int)blockIdx.x, src, tau_or_npts, n_t_or_pcap, dim, subsample, mode,
+                                                 normalise, thresh, L, p_max, n_points, out);
     } else {
         RETRY_SCAN_BEGIN(NT, out.status, n_win)
             if (retry_ctr && threadIdx.x == 0) atomicAdd(retry_ctr + 1, 1ull);
-            rips_cloud_window<NT, W, WT>(smem, win, src, tau_or_npts, n_t_or_pcap, dim, subsample, mode, normalise,
-                                         thresh, L, p_max, n_points, out);
+            rips_cloud_window<NT, W, WT, false>(smem, win, src, tau_or_npts, n_t_or_pcap, dim, subsample, mode, normalise,
+                                                thresh, L, p_max, n_points, out);
         RETRY_SCAN_END()
     }
     if (span && threadIdx.x == 0) {                        // device-scope atomics only: a fence would write L2 back
@@ -1861,13 +2143,16 @@ __device__ __forceinline__ void eeg_one_window(unsigned char* smem, const Window
 
 // RETRY = false: one window per workgroup and NO loop over windows -- with the loop the compiler hoists the address
 // arithmetic of the window fetch out of it and the kernel spills 141 registers (measured).
-// Launch bound: never ONE wave per SIMD.  At that bound the compiler moves values into the accumulation registers
-// (AGPRs), and the widening pass of the streaming form then delivered wrong diagrams for every window it redid
-// (deterministically; tools/dbg_fused.py) while the same source at two waves per SIMD (256 VGPRs, no AGPRs) is
-// exact -- not understood beyond that, so every variant of this kernel stays at >= 2 waves per SIMD and
-// tests/test_gpu_parity.py::test_fused_eeg_window_512_classes covers the widest one.
+// Launch bound: never ONE wave per SIMD -- at that bound hipcc keeps the f64 MFMA accumulators of cd_window_products in
+// AGPRs and mis-places the wait in front of the first v_accvgpr_read of one path (a proven compiler fault: see the
+// note in corr_dist_dev.h; the sweep and its LDS hand-overs are not involved -- the distance matrix itself comes out
+// wrong).  Every variant of this kernel stays at >= 2 waves per SIMD (no AGPRs: checked by a CPU test on the code
+// object) and tests/test_gpu_parity.py::test_fused_eeg_window_512_classes covers the widest one.
+#ifndef TDA_EEG_WIDE_WAVES
+#define TDA_EEG_WIDE_WAVES 2     // (tools/probes/wide_waves_repro.py builds with 1 to reproduce the fault)
+#endif
 template <int NB, bool RES, int W, bool RETRY, typename WT>
-__global__ void __launch_bounds__(256, (W > 2 || RETRY) ? 2 : (RES ? 3 : 4))
+__global__ void __launch_bounds__(256, (W > 2 || RETRY) ? TDA_EEG_WIDE_WAVES : (RES ? 3 : 4))
 eeg_window_kernel(WindowSource windows, int n_win, int n_ch, int n_t, float thresh, RipsLayout L, RipsOut out,
                   double* __restrict__ dist, double* __restrict__ corr, unsigned long long* __restrict__ retry_ctr)
 {
@@ -1908,6 +2193,21 @@ static RipsLayout make_layout(int n, int psi_bytes_per_edge, int aux_bytes, int 
     const int nb = (NT == 256 && n <= 64) ? 2048 : (NT == 512 ? CLOUD_NB : 8192);
     if (misc_bytes < MISC_SORTCNT + 2 * nb) misc_bytes = MISC_SORTCNT + 2 * nb;
     L.total = align16(L.off_misc + misc_bytes) + GUARD_BYTES;
+    L.off_psi = 0; L.psi_cap = E; L.off_cursor = L.off_misc + MISC_SORTCNT; L.off_rscr = L.off_misc;
+    L.guard[0] = L.off_rank; L.guard[1] = L.off_ord; L.guard[2] = L.off_aux; L.guard[3] = L.off_misc; L.guard[4] = L.total;
+    L.n_guard = 5;
+    return L;
+}
+
+static RipsLayout make_narrow_layout(int n, int dim)      // total == 0: the cloud does not fit the fixed layout (struct NL)
+{
+    static_assert(MISC_BYTES(32) == 8752 + 8 * 32, "NL::MISC assumes this");
+    RipsLayout L;
+    L.off_rank = NL::RANK; L.off_psi = NL::PSI; L.off_members = NL::MEMBERS; L.off_cursor = NL::CURSOR; L.off_rscr = NL::RSCR;
+    L.off_aux = NL::AUX; L.off_misc = NL::MISC; L.psi_cap = NL::REGION; L.off_ord = 0;
+    L.total = (n <= NARROW_PMAX && dim <= NARROW_DIM) ? NL::TOTAL : 0;
+    L.guard[0] = NL::PSI; L.guard[1] = NL::MISC; L.guard[2] = NL::AUX; L.guard[3] = NL::TOTAL; L.guard[4] = NL::TOTAL;
+    L.n_guard = 4;
     return L;
 }
 
@@ -2083,15 +2383,17 @@ tda_status launch_eeg_sliding(tda_ctx* ctx, const double* sig, int n_rec, int n_
     return launch_eeg_source(ctx, src, n_out, n_ch, win_len, thresh, dist, corr, h0, h0_cap, h0_cnt, h1, h1_cap, h1_cnt, status, st);
 }
 
-template <int W, typename WT>
+template <int W, typename WT, bool NARROW = false>
 static tda_status launch_cloud_t(tda_ctx* ctx, const double* src, const int* aux, int n_win, int n_t_or_pcap,
                                  int dim, int subsample, int mode, int normalise, float thresh, int p_max,
                                  int* n_points, RipsOut out, hipStream_t st, int retry_only)
 {
-    const int NT = CLOUD_NT;
-    const RipsLayout L = make_layout(p_max, W * (int)sizeof(WT), p_max * dim * 8, NT);
-    if (L.total > LDS_MAX) TDA_FAIL(ctx, TDA_ERR_UNSUPPORTED, "point cloud too large for LDS");
-    auto kern = retry_only ? rips_cloud_kernel<CLOUD_NT, W, WT, true> : rips_cloud_kernel<CLOUD_NT, W, WT, false>;
+    const int NT = NARROW ? NARROW_NT : CLOUD_NT;
+    const RipsLayout L = NARROW ? make_narrow_layout(p_max, dim)
+                                : make_layout(p_max, W * (int)sizeof(WT), p_max * dim * 8, NT);
+    if (L.total > LDS_MAX || L.total == 0) TDA_FAIL(ctx, TDA_ERR_UNSUPPORTED, "point cloud too large for LDS");
+    auto kern = retry_only ? rips_cloud_kernel<CLOUD_NT, W, WT, true, false>
+                           : rips_cloud_kernel<(NARROW ? NARROW_NT : CLOUD_NT), W, WT, false, NARROW>;
     if (L.total > 48 * 1024)
         TDA_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, L.total));
@@ -2138,7 +2440,13 @@ tda_status launch_rips_cloud(tda_ctx* ctx, const double* src, const int* aux, in
     const bool do_first = ctx->retry_policy != TDA_RETRY_ONLY, do_ladder = ctx->retry_policy != TDA_RETRY_FIRST_PASS;
     int first = 1;
     if (ctx->words_cloud == 1) {
-        if (do_first)
+        // first pass: 32 class bits, the narrow layout (three workgroups per CU) whenever the cloud size allows it
+        static const bool no_narrow = getenv("TDA_CLOUD_WIDE_FIRST") != nullptr;
+        const bool narrow = !no_narrow && make_narrow_layout(p_max, dim).total != 0;
+        if (do_first && narrow)
+            rc = launch_cloud_t<1, u32, true>(ctx, src, aux, n_win, n_t_or_pcap, dim, subsample, mode, normalise, th, p_max,
+                                              n_points, out, st, 0);
+        else if (do_first)
             rc = launch_cloud_t<1, u32>(ctx, src, aux, n_win, n_t_or_pcap, dim, subsample, mode, normalise, th, p_max,
                                         n_points, out, st, 0);
         first = 0;

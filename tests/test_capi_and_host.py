@@ -200,3 +200,28 @@ def test_bench_launch_contract_without_gpu():
         r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--no-cpu"], env=env,
                            capture_output=True, text=True, timeout=300)
         assert r.returncode == 2 and "GPU(s) visible" in r.stderr
+
+
+def test_mfma_kernels_keep_accumulators_in_vgprs(tmp_path):
+    """Condition under which the f64 MFMA code of the product is known to be exact (csrc/corr_dist_dev.h, COMPILER
+    FAULT): hipcc mis-places the wait in front of the first v_accvgpr_read after a v_mfma_f64 when the accumulators
+    live in AGPRs.  No kernel of the shipped code objects may use AGPRs."""
+    import shutil
+    import subprocess
+    objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    readelf = "/opt/rocm/lib/llvm/bin/llvm-readelf"
+    lib = os.path.join(ROOT, "tda_eeg_audio_amd", "libtdaeeg.so")
+    if not (os.path.exists(objdump) and os.path.exists(readelf) and os.path.exists(lib)):
+        pytest.skip("ROCm binutils or the built library are not here")
+    shutil.copy(lib, tmp_path / "lib.so")
+    subprocess.run([objdump, "--offloading", "lib.so"], cwd=tmp_path, check=True, capture_output=True)
+    seen = 0
+    for f in sorted(os.listdir(tmp_path)):
+        if "gfx950" not in f:
+            continue
+        notes = subprocess.run([readelf, "--notes", f], cwd=tmp_path, check=True, capture_output=True, text=True).stdout
+        counts = re.findall(r"\.agpr_count:\s+(\d+)\s+(?:.*\n)*?\s+\.name:\s+(\S+)", notes)
+        for n, name in counts:
+            seen += 1
+            assert int(n) == 0, f"{name} uses {n} AGPRs"
+    assert seen >= 40, seen          # every kernel of the five code objects was looked at

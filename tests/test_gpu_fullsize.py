@@ -134,7 +134,9 @@ def test_config4_audio_and_config5_pairs(ctx):
     c0 = aud.c0.cpu().numpy()
     assert np.all(c0 <= P) and np.all(c0 >= P - 2)           # P-1 merges (+1 essential), coincident points dropped
     h0 = aud.h0.cpu().numpy(); h1 = aud.h1.cpu().numpy(); c1 = aud.c1.cpu().numpy()
-    assert np.all(h0[:, :, 1][np.arange(128)[None, :] < c0[:, None]] <= np.float32(np.sqrt(3.0)) + 0 * 1.0) or True
+    # the normalised cloud lies in the unit cube: no finite H0 death beyond its diagonal (essential rows are +inf)
+    fin = (np.arange(h0.shape[1])[None, :] < c0[:, None]) & np.isfinite(h0[:, :, 1])
+    assert np.all(h0[:, :, 1][fin] <= float(np.float32(np.sqrt(3.0))))
     rng = np.random.default_rng(1)
     for w in rng.choice(len(wins), 80, replace=False):
         (o0, o1), Pw = port.audio_persistence(wins[w], int(tau_h[w]))

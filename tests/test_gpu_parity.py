@@ -596,7 +596,9 @@ def test_pipeline_step_vs_oracle_and_lanes(ctx):
     torch.cuda.synchronize()
     for k in range(5):
         assert np.array_equal(got[k].result().cpu().numpy(), serial[k], equal_nan=True), k
-    assert lanes.repairs == 0
+    # (a batch whose first pass leaves a flag -- a window whose classes outlive the narrow layout of the audio kernel, or
+    # more classes alive than bits -- is re-run with the full ladder before it is published: equal to the serial result above)
+    assert lanes.repairs <= len(batches)
     # the same through captured HIP graphs (one per lane and input buffer pair), replayed twice
     glanes = pipeline.Lanes(2, n_win, seg_off, dev, graph=True)
     for rnd in range(2):

@@ -65,3 +65,14 @@ def test_lds_guard_build_clean():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "stress_parity.py")], env=env, capture_output=True,
                        text=True, timeout=600)
     assert r.returncode == 0 and "STRESS OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_bounded_polls_report_instead_of_hanging():
+    """The cross-wave hand-overs of the sweep poll LDS words (the turn of phase a, the done flags of phase c).  Every
+    poll is bounded (TDA_POLL_LIMIT): with a dependency broken on purpose (guard build, tda_debug_inject) the windows
+    come back with TDA_WIN_NOT_CONVERGED instead of hanging the GPU."""
+    lib = os.path.join(ROOT, "tda_eeg_audio_amd", "libtdaeeg_dbg.so")
+    assert os.path.exists(lib), "guard build missing: python -c 'import __graft_entry__ as g; g.build()'"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "probes", "poll_fault_inject.py")],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "POLL GUARD OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]

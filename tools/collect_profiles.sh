@@ -19,6 +19,11 @@ export TMPDIR=/tmp
 SMALL="bench.py --no-cpu --no-extras --recordings 236 --steps 2 --warmup 1 --lanes 1 --no-graph --per-band"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_stats -o stats -- python3 bench.py --no-cpu --no-extras --steps 10 --warmup 2 > $OUT/${TAG}_bench_under_rocprof.json 2> $OUT/prof_stats.err
 echo "stats pass done"
+# 1b. the same with ONE pass in flight and eager launches: the dominant kernel's launches do not overlap the kernels of
+#     other passes, so its average duration in this CSV fits inside ms_per_step and `roofline.frac` can be recomputed
+#     from the tracked file alone (alg_bytes_per_launch / avg duration / 8 TB/s)
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_stats1 -o stats1 -- python3 bench.py --lanes 1 --no-graph --no-cpu --no-extras --steps 10 --warmup 2 > $OUT/${TAG}_bench_lanes1_under_rocprof.json 2> $OUT/prof_stats1.err
+echo "single-lane stats pass done"
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/prof_fetch -o fetch -- python3 $SMALL > /dev/null 2> $OUT/prof_fetch.err
 echo "FETCH_SIZE pass done"
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/prof_write -o write -- python3 $SMALL > /dev/null 2> $OUT/prof_write.err
@@ -35,5 +40,5 @@ done
 python3 tools/summarize_profiles.py $OUT $TAG
 python3 tools/summarize_counters.py $OUT $TAG
 # the raw traces are large; the summaries above are what travels back
-rm -rf $OUT/prof_stats/*/ $OUT/prof_fetch $OUT/prof_write $OUT/pmc_sq1 $OUT/pmc_sq2 $OUT/pmc_sq3
-find $OUT/prof_stats -name "*trace*" -delete 2>/dev/null || true
+rm -rf $OUT/prof_stats/*/ $OUT/prof_stats1/*/ $OUT/prof_fetch $OUT/prof_write $OUT/pmc_sq1 $OUT/pmc_sq2 $OUT/pmc_sq3
+find $OUT/prof_stats $OUT/prof_stats1 -name "*trace*" -delete 2>/dev/null || true

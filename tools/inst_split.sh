@@ -10,7 +10,7 @@ out = sys.argv[1]
 rows = defaultdict(dict)
 for path in glob.glob(os.path.join(out, "pmc_split", "**", "*counter_collection.csv"), recursive=True):
     for r in csv.DictReader(open(path)):
-        if "rips_cloud_kernel<512, 1, unsigned int, false" in r["Kernel_Name"]:
+        if "rips_cloud_kernel<512, 1, unsigned int, false" in r["Kernel_Name"] or "rips_cloud_kernel<384, 1, unsigned int, false" in r["Kernel_Name"]:
             rows[int(r["Dispatch_Id"])][r["Counter_Name"]] = float(r["Counter_Value"])
 stops = ["keys", "ranking", "a:mask", "b:cand-barrier", "b:walk", "b:publish", "c:deps", "d:closure", "d:list", "d:reduce", "d:table", "all"]
 if os.environ.get("TDA_SPLIT_PHASES_OF"):

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Condense the rocprofv3 outputs of tools/collect_profiles.sh:
-   <out>/<tag>_kernel_stats.csv   per-kernel calls / total / average / percentage (from --stats)
+   <out>/<tag>_kernel_stats.csv   per-kernel calls / total / average / percentage (from --stats; five passes in flight)
+   <out>/<tag>_kernel_stats_lanes1.csv   the same with one pass in flight, eager launches (per-launch times fit the step)
    <out>/<tag>_pmc_summary.json   FETCH_SIZE / WRITE_SIZE per launch, averaged per kernel name
    <out>/traffic.json             HBM bytes per launch of the first-pass kernel of each bench stage
 """
@@ -20,16 +21,18 @@ def short(name):
     return name.replace("void ", "")
 
 
-stats = find("prof_stats", "*kernel_stats.csv")
-if stats:
+for d, suffix in (("prof_stats", "kernel_stats"), ("prof_stats1", "kernel_stats_lanes1")):
+    stats = find(d, "*kernel_stats.csv")
+    if not stats:
+        continue
     rows = list(csv.DictReader(open(stats)))
-    with open(os.path.join(out, f"{tag}_kernel_stats.csv"), "w") as f:
+    with open(os.path.join(out, f"{tag}_{suffix}.csv"), "w") as f:
         w = csv.writer(f)
         w.writerow(["kernel", "calls", "total_ns", "avg_ns", "percent", "min_ns", "max_ns"])
         for r in rows:
             w.writerow([short(r["Name"]), r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"],
                         r.get("MinNs", ""), r.get("MaxNs", "")])
-    print("kernel stats:", len(rows), "kernels")
+    print(suffix, ":", len(rows), "kernels")
 
 pmc = {}
 for d, ctr in (("prof_fetch", "FETCH_SIZE"), ("prof_write", "WRITE_SIZE")):
