@@ -80,15 +80,20 @@ tda_status tda_set_class_words(tda_ctx* ctx, int words_dm, int words_cloud);
  * ONE_STEP: the first pass and ONE widening pass (the next rung of the ladder: 128 bits for matrices, 64 for
  *   clouds), which catches nearly every flagged window and still fits beside the other kernels of a busy GPU; the
  *   wide rungs (up to 95 KB of LDS and 256 VGPRs per workgroup, which wait for a nearly empty CU even when they have
- *   nothing to redo) are left to a later RETRY_ONLY call for the batches whose statuses still carry the bit. */
+ *   nothing to redo) are left to a later RETRY_ONLY call for the batches whose statuses still carry the bit.
+ * The ladders end in a pass that keeps the class vectors in HBM and has no capacity limit (8,192 classes cover every
+ * complex on 128 points): under AUTO and RETRY_ONLY no window keeps TDA_WIN_CLASS_OVERFLOW, as ripser never refuses an
+ * input.  LAST_RUNG launches only that pass (on the flagged windows). */
 #define TDA_RETRY_AUTO       0
 #define TDA_RETRY_FIRST_PASS 1
 #define TDA_RETRY_ONLY       2
 #define TDA_RETRY_ONE_STEP   3
+#define TDA_RETRY_LAST_RUNG  4   /* only the last rung (class vectors in HBM) on the flagged windows: for tests */
 tda_status tda_set_retry_policy(tda_ctx* ctx, int policy);
-/* Optional accounting of the widening passes: dev_counters = DEVICE u64[2] (or NULL to stop).  Every window a
+/* Optional accounting of the widening passes: dev_counters = DEVICE u64[4] (or NULL to stop).  Every window a
  * widening pass redoes adds one to [0] (distance-matrix input, tda_rips_dm_batch) or [1] (point clouds,
- * tda_takens_rips_batch / tda_cloud_rips_batch); a window that climbs two rungs of the ladder counts twice.
+ * tda_takens_rips_batch / tda_cloud_rips_batch); a window that climbs two rungs of the ladder counts twice; [2] counts
+ * the windows redone by the last rung (class vectors in HBM, no capacity limit).
  * The reference has no counterpart (ripser's columns grow on the heap); bench.py reports it as windows_repaired. */
 tda_status tda_set_retry_counter(tda_ctx* ctx, void* dev_counters);
 

@@ -149,7 +149,7 @@ class Context:
     def set_class_words(self, words_dm=2, words_cloud=1):
         self.check(self.lib.tda_set_class_words(self.h, words_dm, words_cloud))
 
-    RETRY_AUTO, RETRY_FIRST_PASS, RETRY_ONLY, RETRY_ONE_STEP = 0, 1, 2, 3
+    RETRY_AUTO, RETRY_FIRST_PASS, RETRY_ONLY, RETRY_ONE_STEP, RETRY_LAST_RUNG = 0, 1, 2, 3, 4
 
     def set_retry_policy(self, policy):
         self.check(self.lib.tda_set_retry_policy(self.h, int(policy)))
@@ -160,7 +160,7 @@ class Context:
         self.check(self.lib.tda_set_h1_order(self.h, int(policy)))
 
     def set_retry_counter(self, dev_ptr):
-        """dev_ptr: device address of a zeroed u64[2] (or None): windows redone by the widening passes."""
+        """dev_ptr: device address of a zeroed u64[4] (or None): windows redone by the widening passes."""
         self.check(self.lib.tda_set_retry_counter(self.h, c_vp(dev_ptr) if dev_ptr else None))
 
     # ---- one-shot kernel probe (bench.py roofline): HIP events around ONE first-pass kernel ----

@@ -27,6 +27,9 @@ tda_status tda_ctx_create(int device_id, tda_ctx** out)
     tda_ctx* c = new (std::nothrow) tda_ctx();
     if (!c) return TDA_ERR_NOMEM;
     c->device = device_id;
+    // scratch of the last rung of the Rips ladders, allocated here so that every entry point stays enqueue-only
+    e = hipMalloc((void**)&c->total_scratch, rips_total_scratch_bytes());
+    if (e != hipSuccess) { g_create_err = std::string("hipMalloc (Rips scratch): ") + hipGetErrorString(e); delete c; return TDA_ERR_HIP; }
     *out = c;
     return TDA_OK;
 }
@@ -35,6 +38,7 @@ void tda_ctx_destroy(tda_ctx* ctx)
 {
     if (!ctx) return;
     if (ctx->ws) (void)hipFree(ctx->ws);
+    if (ctx->total_scratch) (void)hipFree(ctx->total_scratch);
     delete ctx;
 }
 
@@ -85,7 +89,7 @@ tda_status tda_set_retry_counter(tda_ctx* ctx, void* dev_counters)
 tda_status tda_set_retry_policy(tda_ctx* ctx, int policy)
 {
     if (!ctx) return TDA_ERR_INVALID;
-    if (policy < TDA_RETRY_AUTO || policy > TDA_RETRY_ONE_STEP) TDA_FAIL(ctx, TDA_ERR_INVALID, "unknown retry policy");
+    if (policy < TDA_RETRY_AUTO || policy > TDA_RETRY_LAST_RUNG) TDA_FAIL(ctx, TDA_ERR_INVALID, "unknown retry policy");
     ctx->retry_policy = policy;
     return TDA_OK;
 }

@@ -14,7 +14,8 @@ struct tda_ctx {
     int words_dm = 2;       // H1 class capacity (x64) for distance-matrix input
     int words_cloud = 1;    // ... for point clouds
     int retry_policy = 0;   // TDA_RETRY_*
-    unsigned long long* retry_ctr = nullptr;   // tda_set_retry_counter: device u64[2]
+    unsigned long long* retry_ctr = nullptr;   // tda_set_retry_counter: device u64[4]
+    unsigned long long* total_scratch = nullptr;   // class vectors of the last rung of the Rips ladders (rips.hip: TOT_SLOTS x 8.3 MB)
     int h1_order = 0;       // TDA_ORDER_*
     // host-API staging workspace (grown on demand, only by the host-pointer twins)
     void* ws = nullptr;
@@ -141,6 +142,7 @@ __device__ __forceinline__ float sortable_f32(u32 s)
 }
 
 // launch-side entry points implemented in the .hip files
+size_t rips_total_scratch_bytes();
 tda_status launch_corr_dist(tda_ctx*, const double*, int, int, int, double*, double*, hipStream_t);
 tda_status launch_corr_dist_sliding(tda_ctx*, const double*, int, int, int, int, double*, double*, int*, hipStream_t);
 tda_status launch_corr_to_dist(tda_ctx*, const double*, int, int, int, double*, hipStream_t);

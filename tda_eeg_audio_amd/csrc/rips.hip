@@ -1706,6 +1706,162 @@ __device__ __forceinline__ void rips_sweep(int n, int E, int Ev, const u16* rank
     out_k0 = k0; out_k1 = k1; out_status = status;
 }
 
+
+// ---------------------------------------------------------------------------------
+// The LAST rung of both class ladders: a sweep that cannot run out of anything.  ripser never refuses an input
+// (scripts/utils.py:131,140); the chunked sweep above keeps its class vectors in LDS and flags a window whose classes
+// do not fit.  This one keeps them in HBM -- one vector of TOT_NW 64-bit words per edge, a bit per class in BIRTH ORDER,
+// never reused: a complex on n <= 128 points has at most E - n + 1 <= 8,001 classes, 8,192 bits hold them all -- and
+// walks the filtration one edge at a time with the same invariants as the chunked sweep (psi[edge] = class of "edge +
+// forest path"; an edge with a common neighbour v* gets psi[a,v*] ^ psi[b,v*]; every other triangle (a,b,v) is
+// tested; a non-zero one kills the youngest class in it = its highest bit, which is substituted out of every vector).
+// No link argument, no chunks, no capacity: a few barriers per edge, tens of milliseconds per window -- it only ever
+// sees the windows every other pass has flagged (lattices, clouds built to have > 64 classes alive at once).
+// Vectors that are zero are not stored: one bit per edge in LDS says so.
+// ---------------------------------------------------------------------------------
+#define TOT_NW 128                    // u64 words per class vector
+#define TOT_SLOTS 8                   // windows in flight = workgroups of the launch (8.3 MB of scratch each)
+#define TOT_SLOT_WORDS ((size_t)8128 * TOT_NW)
+
+template <int NT, class KEYFN>
+__device__ void rips_sweep_total(int n, int E, int Ev, const u16* rank, const u16* ord, float* bkey, unsigned char* misc,
+                                 u64* __restrict__ psi_g, KEYFN keyfn, double* h0, int h0_cap, double* h1, int h1_cap,
+                                 int& out_k0, int& out_k1, int& out_status)
+{
+    constexpr int NWV = NT / 64;
+    const int tid = threadIdx.x, lane = tid & 63, wave = uni(tid >> 6);
+    u64* adj = reinterpret_cast<u64*>(misc + MISC_ADJ);                  // adj[2 v + w]
+    int* comp = reinterpret_cast<int*>(misc + MISC_COMP);                // component label of every vertex
+    u32* flags = reinterpret_cast<u32*>(misc + MISC_WV);                 // [8] a wave found a non-zero triangle; [8] scalars
+    u64* yv = reinterpret_cast<u64*>(misc + MISC_LIST);                  // [TOT_NW] the killing vector
+    u64* cur = yv + TOT_NW;                                              // [TOT_NW] psi of the current edge
+    u32* nzbit = reinterpret_cast<u32*>(misc + MISC_ADJ + 4096);         // [256] vector of edge r is stored (non-zero)
+    u32* alivebit = nzbit + 256;                                         // [256] class c is alive
+    static_assert(MISC_LIST_BYTES >= 2 * TOT_NW * 8, "scratch of the total sweep");      // (+ 2 KB behind MISC_BRANK: total_layout)
+    for (int i = tid; i < 256; i += NT) { adj[i] = 0ull; nzbit[i] = 0u; alivebit[i] = 0u; }
+    for (int v = tid; v < 128; v += NT) comp[v] = v;
+    __syncthreads();
+    int k0 = 0, k1 = 0, merges = 0, nborn = 0, nalive = 0;
+    auto stored = [&](int rr) { return (nzbit[rr >> 5] >> (rr & 31)) & 1u; };
+    for (int r = 0; r < Ev; ++r) {
+        const u32 pk = (u32)uni((int)ord[r]);
+        const int a = (int)(pk >> 8), b = (int)(pk & 255u);
+        const u64 M0 = uni64(adj[2 * a] & adj[2 * b]), M1 = uni64(adj[2 * a + 1] & adj[2 * b + 1]);
+        if ((M0 | M1) == 0ull) {
+            const int ca = uni(comp[a]), cb = uni(comp[b]);
+            const float key = keyfn(r, a, b);
+            __syncthreads();                                             // (labels read before anybody relabels)
+            if (ca != cb) {                                              // negative edge: H0 death
+                for (int v = tid; v < n; v += NT) if (comp[v] == cb) comp[v] = ca;
+                if (key != 0.0f) {
+                    if (tid == 0 && k0 < h0_cap) { h0[2 * k0] = 0.0; h0[2 * k0 + 1] = (double)key; }
+                    ++k0;
+                }
+                ++merges;
+            } else {                                                     // a class is born: the next bit
+                const int c = nborn++;
+                if (tid == 0) { bkey[c] = key; nzbit[r >> 5] |= 1u << (r & 31); alivebit[c >> 5] |= 1u << (c & 31); }
+                for (int w = tid; w < TOT_NW; w += NT) psi_g[(size_t)r * TOT_NW + w] = (w == (c >> 6)) ? 1ull << (c & 63) : 0ull;
+                ++nalive;
+            }
+        } else if (nalive > 0) {
+            const int vstar = M0 ? __builtin_ctzll(M0) : 64 + __builtin_ctzll(M1);
+            const int s1 = uni((int)rank[pair_index(a, vstar)]), s2 = uni((int)rank[pair_index(b, vstar)]);
+            const bool z1 = !stored(s1), z2 = !stored(s2);
+            u64 bw = 0ull;
+            if (tid < TOT_NW) {
+                bw = (z1 ? 0ull : psi_g[(size_t)s1 * TOT_NW + tid]) ^ (z2 ? 0ull : psi_g[(size_t)s2 * TOT_NW + tid]);
+                cur[tid] = bw;
+            }
+            if (lane == 0) flags[wave] = 0u;
+            __syncthreads();
+            if (__ballot(bw != 0ull) != 0ull && lane == 0) flags[wave] = 1u;
+            __syncthreads();
+            bool nzr = false;
+#pragma unroll
+            for (int w = 0; w < NWV; ++w) nzr = nzr || flags[w] != 0u;
+            if (nzr) {
+                if (tid < TOT_NW) psi_g[(size_t)r * TOT_NW + tid] = bw;
+                if (tid == 0) nzbit[r >> 5] |= 1u << (r & 31);
+            }
+            // the other triangles, NWV at a time (one per wave); a kill changes the table: the same ones are looked at again
+            u64 R0 = M0, R1 = M1;
+            if (vstar < 64) R0 &= ~(1ull << vstar); else R1 &= ~(1ull << (vstar - 64));
+            float keyr = 0.f;
+            bool have_key = false;
+            while ((R0 | R1) != 0ull && nalive > 0) {
+                __syncthreads();                                         // flags / cur of the round before are done with
+                // wave w takes the w-th remaining common neighbour
+                int v = -1;
+                {
+                    u64 t0 = R0, t1 = R1;
+                    for (int k = 0; k < wave && (t0 | t1); ++k) { if (t0) t0 &= t0 - 1ull; else t1 &= t1 - 1ull; }
+                    if (t0) v = __builtin_ctzll(t0); else if (t1) v = 64 + __builtin_ctzll(t1);
+                }
+                u64 y0 = 0ull, y1 = 0ull;
+                if (v >= 0) {
+                    const int ja = uni((int)rank[pair_index(a, v)]), jb = uni((int)rank[pair_index(b, v)]);
+                    y0 = cur[lane]; y1 = cur[lane + 64];
+                    if (stored(ja)) { y0 ^= psi_g[(size_t)ja * TOT_NW + lane]; y1 ^= psi_g[(size_t)ja * TOT_NW + lane + 64]; }
+                    if (stored(jb)) { y0 ^= psi_g[(size_t)jb * TOT_NW + lane]; y1 ^= psi_g[(size_t)jb * TOT_NW + lane + 64]; }
+                }
+                const bool wnz = __ballot((y0 | y1) != 0ull) != 0ull;
+                if (lane == 0) flags[wave] = wnz ? 1u : 0u;
+                __syncthreads();
+                int first = -1;
+#pragma unroll
+                for (int w = NWV - 1; w >= 0; --w) if (flags[w]) first = w;
+                if (first < 0) {                                         // these NWV triangles are trivial: on to the next ones
+                    for (int k = 0; k < NWV && (R0 | R1); ++k) { if (R0) R0 &= R0 - 1ull; else R1 &= R1 - 1ull; }
+                    continue;
+                }
+                if (wave == first) {                                     // the killer: publish the vector and its youngest class
+                    yv[lane] = y0; yv[lane + 64] = y1;
+                    int m = y1 ? 64 * (lane + 64) + 63 - __builtin_clzll(y1) : (y0 ? 64 * lane + 63 - __builtin_clzll(y0) : -1);
+                    m = wave_max_i32_dpp(m);
+                    if (lane == 0) flags[8] = (u32)m;
+                }
+                __syncthreads();
+                const int c = (int)flags[8];
+                if (!have_key) { keyr = keyfn(r, a, b); have_key = true; }
+                const float birth = bkey[c];
+                if (keyr > birth) {
+                    if (tid == 0 && k1 < h1_cap) { h1[2 * k1] = (double)birth; h1[2 * k1 + 1] = (double)keyr; }
+                    ++k1;
+                }
+                if (tid == 0) alivebit[c >> 5] &= ~(1u << (c & 31));
+                --nalive;
+                // substitute the class out of every stored vector up to this edge (one vector per wave and trip)
+                for (int rr = wave; rr <= r; rr += NWV) {
+                    if (!stored(rr)) continue;
+                    const u64 wc = psi_g[(size_t)rr * TOT_NW + (c >> 6)];
+                    if (!((wc >> (c & 63)) & 1ull)) continue;
+                    psi_g[(size_t)rr * TOT_NW + lane] ^= yv[lane];
+                    psi_g[(size_t)rr * TOT_NW + lane + 64] ^= yv[lane + 64];
+                }
+                __syncthreads();                                         // (global stores of a workgroup are visible to it behind a barrier)
+                if (tid < TOT_NW) cur[tid] = stored(r) ? psi_g[(size_t)r * TOT_NW + tid] : 0ull;
+            }
+        }
+        __syncthreads();
+        if (tid == 0) { adj[2 * a + (b >> 6)] |= 1ull << (b & 63); adj[2 * b + (a >> 6)] |= 1ull << (a & 63); }
+        __syncthreads();
+    }
+    int status = 0;
+    const int ncomp = n - merges;
+    for (int i = 0; i < ncomp; ++i) {
+        if (k0 < h0_cap && tid == 0) { h0[2 * k0] = 0.0; h0[2 * k0 + 1] = (double)INFINITY; }
+        ++k0;
+    }
+    for (int c = 0; c < nborn; ++c)
+        if ((alivebit[c >> 5] >> (c & 31)) & 1u) {
+            if (k1 < h1_cap && tid == 0) { h1[2 * k1] = (double)bkey[c]; h1[2 * k1 + 1] = (double)INFINITY; }
+            ++k1;
+        }
+    if (k1 > h1_cap) status |= TDA_WIN_H1_TRUNCATED;
+    out_k0 = k0; out_k1 = k1; out_status = status;
+}
+
 // ---------------------------------------------------------------------------------
 // distance-matrix flavour (EEG): LDS = [S | psi] [ord] [rank] [skey] [misc]
 // ---------------------------------------------------------------------------------
@@ -1715,9 +1871,9 @@ struct KeyFromLds {
 };
 
 // everything after the keys: key32[e] (flat edge order) and vmax[v] = max_u key(v,u) are in LDS, barrier passed
-template <int NT, int NVW, int W, typename WT>
+template <int NT, int NVW, int W, typename WT, bool TOTAL = false>
 __device__ void rips_dm_rest(unsigned char* smem, const int win, int n, float thresh, const u32* vmax, u32 kmin_thread,
-                             const RipsLayout& L, const RipsOut& out)
+                             const RipsLayout& L, const RipsOut& out, u64* psi_g = nullptr)
 {
     const int tid = threadIdx.x;
     const int E = tri2(n);
@@ -1742,6 +1898,11 @@ __device__ void rips_dm_rest(unsigned char* smem, const int win, int n, float th
     guard_write(smem, L);
     int k0, k1, st;
     KeyFromLds kf{skey};
+    if constexpr (TOTAL)
+        rips_sweep_total<NT>(n, E, Ev, rank, ord, reinterpret_cast<float*>(smem), misc, psi_g, kf,
+                             out.h0 + (size_t)win * out.h0_cap * 2, out.h0_cap,
+                             out.h1 + (size_t)win * out.h1_cap * 2, out.h1_cap, k0, k1, st);
+    else
     rips_sweep<NT, NVW, W, WT, false>(n, E, Ev, rank, ord, psi, 0, misc, kf,
                        out.h0 + (size_t)win * out.h0_cap * 2, out.h0_cap,
                        out.h1 + (size_t)win * out.h1_cap * 2, out.h1_cap, k0, k1, st);
@@ -1753,9 +1914,9 @@ __device__ void rips_dm_rest(unsigned char* smem, const int win, int n, float th
     if (tid == 0) { out.h0_cnt[win] = k0; out.h1_cnt[win] = k1; out.status[win] = st; }
 }
 
-template <int NT, int NVW, int W, typename WT>
+template <int NT, int NVW, int W, typename WT, bool TOTAL = false>
 __device__ void rips_dm_window(unsigned char* smem, const int win, const double* __restrict__ dm, int n, float thresh,
-                               int symmetrise, const RipsLayout& L, const RipsOut& out)
+                               int symmetrise, const RipsLayout& L, const RipsOut& out, u64* psi_g = nullptr)
 {
     const int tid = threadIdx.x;
     const int E = tri2(n);
@@ -1785,7 +1946,7 @@ __device__ void rips_dm_window(unsigned char* smem, const int win, const double*
     }
     __syncthreads();
     PROF_MARK(0);
-    rips_dm_rest<NT, NVW, W, WT>(smem, win, n, thresh, vmax, kmin_thread, L, out);
+    rips_dm_rest<NT, NVW, W, WT, TOTAL>(smem, win, n, thresh, vmax, kmin_thread, L, out, psi_g);
 }
 
 #ifdef TDA_DEBUG_PTS
@@ -1892,11 +2053,11 @@ rips_dm_kernel(const double* __restrict__ dm, int n_win, int n, float thresh, in
     }
 }
 
-template <int NT, int W, typename WT, bool NARROW>
+template <int NT, int W, typename WT, bool NARROW, bool TOTAL = false>
 __device__ void rips_cloud_window(unsigned char* smem, const int win, const double* __restrict__ src,
                                   const int* __restrict__ tau_or_npts, int n_t_or_pcap, int dim, int subsample,
                                   int mode, int normalise, float thresh, const RipsLayout& L, int p_max,
-                                  int* __restrict__ n_points, const RipsOut& out)
+                                  int* __restrict__ n_points, const RipsOut& out, u64* psi_g = nullptr)
 {
     const int tid = threadIdx.x;
     u32* key32 = reinterpret_cast<u32*>(smem);
@@ -2005,7 +2166,9 @@ __device__ void rips_cloud_window(unsigned char* smem, const int win, const doub
     PROF_STOP(2, if (tid == 0) { out.h0_cnt[win] = 0; out.h1_cnt[win] = 0; out.status[win] = 0; });
     guard_write(smem, L);
     int k0, k1, st;
-    if (P <= 64)
+    if constexpr (TOTAL)
+        rips_sweep_total<NT>(P, E, Ev, rank, ord, reinterpret_cast<float*>(smem), misc, psi_g, kf, h0, out.h0_cap, h1, out.h1_cap, k0, k1, st);
+    else if (P <= 64)
         rips_sweep<NT, 1, W, WT, NARROW>(P, E, Ev, rank, ord, psi, NL::REGION, misc, kf, h0, out.h0_cap, h1, out.h1_cap, k0, k1, st);
     else
         rips_sweep<NT, 2, W, WT, NARROW>(P, E, Ev, rank, ord, psi, NL::REGION, misc, kf, h0, out.h0_cap, h1, out.h1_cap, k0, k1, st);
@@ -2062,6 +2225,36 @@ rips_cloud_kernel(const double* __restrict__ src, const int* __restrict__ tau_or
             atomicExch(&span[1], 0ull);
         }
     }
+}
+
+// The last rung (rips_sweep_total): TOT_SLOTS workgroups walk the status words and redo what is still flagged, each with
+// its own 8.3 MB of HBM for the class vectors.
+template <int NT>
+__global__ void __launch_bounds__(NT, 2)
+rips_dm_total_kernel(const double* __restrict__ dm, int n_win, int n, float thresh, int symmetrise, RipsLayout L,
+                     RipsOut out, u64* __restrict__ scratch, unsigned long long* __restrict__ retry_ctr)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    u64* psi_g = scratch + (size_t)blockIdx.x * TOT_SLOT_WORDS;
+    RETRY_SCAN_BEGIN(NT, out.status, n_win)
+        if (retry_ctr && threadIdx.x == 0) atomicAdd(retry_ctr + 2, 1ull);
+        rips_dm_window<NT, 2, 1, u32, true>(smem, win, dm, n, thresh, symmetrise, L, out, psi_g);
+    RETRY_SCAN_END()
+}
+template <int NT>
+__global__ void __launch_bounds__(NT, 2)
+rips_cloud_total_kernel(const double* __restrict__ src, const int* __restrict__ tau_or_npts, int n_win, int n_t_or_pcap,
+                        int dim, int subsample, int mode, int normalise, float thresh, RipsLayout L, int p_max,
+                        int* __restrict__ n_points, RipsOut out, u64* __restrict__ scratch,
+                        unsigned long long* __restrict__ retry_ctr)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    u64* psi_g = scratch + (size_t)blockIdx.x * TOT_SLOT_WORDS;
+    RETRY_SCAN_BEGIN(NT, out.status, n_win)
+        if (retry_ctr && threadIdx.x == 0) atomicAdd(retry_ctr + 2, 1ull);
+        rips_cloud_window<NT, 1, u32, false, true>(smem, win, src, tau_or_npts, n_t_or_pcap, dim, subsample, mode, normalise,
+                                                   thresh, L, p_max, n_points, out, psi_g);
+    RETRY_SCAN_END()
 }
 
 // ---------------------------------------------------------------------------------
@@ -2244,6 +2437,32 @@ static tda_status launch_dm_t(tda_ctx* ctx, const double* dm, int n_win, int n, 
 }
 
 static const int LDS_MAX = 160 * 1024;
+
+size_t rips_total_scratch_bytes() { return (size_t)TOT_SLOTS * TOT_SLOT_WORDS * sizeof(u64); }
+
+// layout of the last rung: the wide layout with 32-bit class words (the area of the class vectors holds the birth lengths,
+// one float per possible class) and 2 KB more behind the class tables for the stored / alive bit maps
+static RipsLayout total_layout(int n, int aux_bytes, int NT)
+{
+    RipsLayout L = make_layout(n, 4, aux_bytes, NT);
+    int need = align16(L.off_misc + MISC_BRANK + 2048) + GUARD_BYTES;
+    const int need_rank = align16(L.off_misc + MISC_SORTCNT + 2 * 8192) + GUARD_BYTES;      // its ranking always has 8,192 buckets
+    if (need < need_rank) need = need_rank;
+    if (L.total < need) { L.total = need; L.guard[4] = L.total; }
+    return L;
+}
+static tda_status launch_dm_total(tda_ctx* ctx, const double* dm, int n_win, int n, float thresh, int symmetrise, RipsOut out,
+                                  hipStream_t st)
+{
+    const RipsLayout L = total_layout(n, n * (n - 1) / 2 * 4, 256);
+    auto kern = rips_dm_total_kernel<256>;
+    if (L.total > 48 * 1024)
+        TDA_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, L.total));
+    hipLaunchKernelGGL(kern, dim3(TOT_SLOTS), dim3(256), L.total, st, dm, n_win, n, thresh, symmetrise, L, out,
+                       ctx->total_scratch, ctx->retry_ctr);
+    TDA_HIP(ctx, hipGetLastError());
+    return TDA_OK;
+}
 #ifndef CLOUD_NT
 #define CLOUD_NT 512           // workgroup size of the point-cloud flavour (one workgroup per CU: LDS)
 #endif
@@ -2261,10 +2480,13 @@ tda_status launch_rips_dm(tda_ctx* ctx, const double* dm, int n_win, int n, doub
     int W = ctx->words_dm < 1 ? 1 : ctx->words_dm;      // (32-bit class words exist in the fused EEG kernel only)
     // largest class capacity that still fits the 160 KiB LDS
     while (W > 1 && make_layout(n, W * 8, n * (n - 1) / 2 * 4, 256).total > LDS_MAX) W >>= 1;
-    const bool do_first = ctx->retry_policy != TDA_RETRY_ONLY, do_ladder = ctx->retry_policy != TDA_RETRY_FIRST_PASS;
+    const bool last_only = ctx->retry_policy == TDA_RETRY_LAST_RUNG;
+    const bool do_first = ctx->retry_policy != TDA_RETRY_ONLY && !last_only;
+    const bool do_ladder = ctx->retry_policy != TDA_RETRY_FIRST_PASS && !last_only;
     const bool one_step = ctx->retry_policy == TDA_RETRY_ONE_STEP;
     rc = TDA_OK;
-    if (n <= 64) {
+    if (last_only) {
+    } else if (n <= 64) {
         if (!do_first) {}
         else if (W == 1) rc = launch_dm_t<1, 1>(ctx, dm, n_win, n, th, symmetrise, out, st);
         else if (W == 2) rc = launch_dm_t<1, 2>(ctx, dm, n_win, n, th, symmetrise, out, st);
@@ -2286,6 +2508,9 @@ tda_status launch_rips_dm(tda_ctx* ctx, const double* dm, int n_win, int n, doub
         if (do_ladder && rc == TDA_OK && W == 1 && make_layout(n, 16, n * (n - 1) / 2 * 4, 256).total <= LDS_MAX)
             rc = launch_dm_t<2, 2>(ctx, dm, n_win, n, th, symmetrise, out, st, 1);
     }
+    // the last rung: whatever is still flagged (more than 512 / 128 classes alive at once) is redone with the class
+    // vectors in HBM -- compute_eeg_persistence never refuses a matrix (scripts/utils.py:140)
+    if (rc == TDA_OK && ((do_ladder && !one_step) || last_only)) rc = launch_dm_total(ctx, dm, n_win, n, th, symmetrise, out, st);
     if (rc != TDA_OK) return rc;
     return order_h1(ctx, h1, h1_cap, h1_cnt, n_win, st);
 }
@@ -2316,6 +2541,7 @@ template <bool RES>
 static tda_status launch_eeg_ladder(tda_ctx* ctx, const WindowSource& win, int n_win, int n_ch, int n_t, float th, RipsOut out,
                                     double* dist, double* corr, hipStream_t st)
 {
+    if (ctx->retry_policy == TDA_RETRY_LAST_RUNG) return TDA_OK;     // (512 bits cover every complex on 48 points: no such rung here)
     const bool do_first = ctx->retry_policy != TDA_RETRY_ONLY, do_ladder = ctx->retry_policy != TDA_RETRY_FIRST_PASS;
     const bool one_step = ctx->retry_policy == TDA_RETRY_ONE_STEP;
     tda_status rc = TDA_OK;
@@ -2437,7 +2663,9 @@ tda_status launch_rips_cloud(tda_ctx* ctx, const double* src, const int* aux, in
     // class capacity ladder: 32 bits (two workgroups per CU for 124-point clouds), then 64, then 128
     // while the table fits LDS; each wider pass only redoes the windows the previous one flagged
     const bool fits128 = make_layout(p_max, 16, p_max * dim * 8, CLOUD_NT).total <= LDS_MAX;
-    const bool do_first = ctx->retry_policy != TDA_RETRY_ONLY, do_ladder = ctx->retry_policy != TDA_RETRY_FIRST_PASS;
+    const bool last_only = ctx->retry_policy == TDA_RETRY_LAST_RUNG;
+    const bool do_first = ctx->retry_policy != TDA_RETRY_ONLY && !last_only;
+    const bool do_ladder = ctx->retry_policy != TDA_RETRY_FIRST_PASS && !last_only;
     int first = 1;
     if (ctx->words_cloud == 1) {
         // first pass: 32 class bits, the narrow layout (three workgroups per CU) whenever the cloud size allows it
@@ -2457,6 +2685,17 @@ tda_status launch_rips_cloud(tda_ctx* ctx, const double* src, const int* aux, in
     if (do_ladder && rc == TDA_OK && fits128 && !(ctx->retry_policy == TDA_RETRY_ONE_STEP && !first))
         rc = launch_cloud_t<2, u64>(ctx, src, aux, n_win, n_t_or_pcap, dim, subsample, mode, normalise, th, p_max,
                                     n_points, out, st, 1);
+    // the last rung: whatever is still flagged (more than 64 / 128 classes alive at once) is redone with the class vectors
+    // in HBM -- compute_audio_persistence never refuses a cloud (scripts/utils.py:131)
+    if (rc == TDA_OK && ((do_ladder && ctx->retry_policy != TDA_RETRY_ONE_STEP) || last_only)) {
+        const RipsLayout L = total_layout(p_max, p_max * dim * 8, CLOUD_NT);
+        auto kern = rips_cloud_total_kernel<CLOUD_NT>;
+        if (L.total > 48 * 1024)
+            TDA_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, L.total));
+        hipLaunchKernelGGL(kern, dim3(TOT_SLOTS), dim3(CLOUD_NT), L.total, st, src, aux, n_win, n_t_or_pcap, dim, subsample, mode,
+                           normalise, th, L, p_max, n_points, out, ctx->total_scratch, ctx->retry_ctr);
+        TDA_HIP(ctx, hipGetLastError());
+    }
     if (rc != TDA_OK) return rc;
     return order_h1(ctx, h1, h1_cap, h1_cnt, n_win, st);
 }

@@ -187,6 +187,14 @@ class Lanes:
                 run_step(eeg_win, audio_win, ws, ctx=ctx, max_lag=max_lag, retry="auto")     # rare: full ladder
                 b.repaired = True
                 self.repairs += 1
+                # verify again before publishing: the full ladder ends in a pass without a capacity limit, so no flag
+                # can be left -- if one is, the rows are not what the reference would give and must not go out
+                ws.flags_host.copy_(ws.seg_flags, non_blocking=True)
+                st.synchronize()
+                if bool(ws.flags_host.any()):
+                    from ._lib import TdaError
+                    raise TdaError("Rips class overflow survived the full ladder (status bit 2 in "
+                                   f"{int((ws.flags_host != 0).sum())} recording-band group(s)): rows withheld")
             b.value = b.post(ws.result) if b.post is not None else ws.result
         b.done = True
 

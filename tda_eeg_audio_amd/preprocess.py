@@ -138,7 +138,7 @@ def recordings_to_features(raw_t, fs, sel_t=None, n_sel_per_rec=None, freq_bands
     (n_win, n_ch, 250) stacks and the distance matrices never exist) -> H1 row order + extract_features -> mean / std
     over each recording's windows.  sel_t: optional int32 window list (r * n_win_per_rec + k, n_sel_per_rec per
     recording, recording-major) -- the drivers' window selection.  Returns (n_rec, 44 * n_bands) float64 tensor in the
-    column order of features/feature_names.txt, and the status words of the last band."""
+    column order of features/feature_names.txt, and the status words of the windows, OR-ed over the bands."""
     import torch
     from . import engine
     ctx = ctx or get_ctx()
@@ -157,6 +157,7 @@ def recordings_to_features(raw_t, fs, sel_t=None, n_sel_per_rec=None, freq_bands
     fe1 = torch.empty_like(fe0)
     seg = torch.arange(0, n_out + 1, k, dtype=torch.int32, device=dev)
     X = torch.empty((n_rec, len(freq_bands), 44), dtype=torch.float64, device=dev)
+    status = torch.zeros(n_out, dtype=torch.int32, device=dev)
     ctx.set_h1_order(ctx.ORDER_DEFERRED)
     try:
         for bi, (name, (lo, hi)) in enumerate(freq_bands.items()):
@@ -167,9 +168,10 @@ def recordings_to_features(raw_t, fs, sel_t=None, n_sel_per_rec=None, freq_bands
             engine.eeg_window_sliding_dev(y.view(n_rec, n_ch, n_s), win, step, sel_t=sel_t, out=dgm, ctx=ctx)
             engine.diagram_finish_dev([(dgm.h0, dgm.c0, False, fe0), (dgm.h1, dgm.c1, True, fe1)], ctx=ctx)
             X[:, bi].copy_(engine.aggregate_dev(fe0, fe1, seg, ctx=ctx))
+            status |= dgm.status                 # (the next band overwrites the words)
     finally:
         ctx.set_h1_order(ctx.ORDER_IN_CALL)
-    return X.view(n_rec, len(freq_bands) * 44), dgm.status
+    return X.view(n_rec, len(freq_bands) * 44), status
 
 
 def eeg_to_distances(eeg, fs, freq_bands=FREQ_BANDS, window_size=WINDOW_SIZE_SEC, overlap=OVERLAP_PERCENT,

@@ -132,9 +132,10 @@ def test_scaling_by_a_power_of_two_scales_the_diagram_exactly(ctx):
 
 
 def test_h1_of_lattices_cube_and_cross_polytope(ctx):
-    """(k-1)^2 rows (1, sqrt 2) for the k x k unit lattice -- up to 81 classes alive at once, i.e. through the widening
-    passes (100 classes on 121 points exceed what fits LDS: status bit 2) --, 5 for the unit cube, none for cross-polytopes (tests/test_oracle_golden.py has the argument); both
-    kernels, both first-pass class widths."""
+    """(k-1)^2 rows (1, sqrt 2) for the k x k unit lattice -- up to 100 classes alive at once, i.e. through the widening
+    passes and, for the 11 x 11 lattice (121 points: the 128-class table does not fit LDS at that size; more than 64
+    classes on a cloud), through the last rung with its class vectors in HBM --, 5 for the unit cube, none for
+    cross-polytopes (tests/test_oracle_golden.py has the argument); both kernels, both first-pass class widths."""
     from test_oracle_golden import lattice
     r2 = np.float64(np.float32(np.sqrt(2.0)))
 
@@ -146,16 +147,13 @@ def test_h1_of_lattices_cube_and_cross_polytope(ctx):
             for k in range(2, 12):
                 P = lattice(k)
                 h0, h1, st = engine.rips_dm_batch(dm(P)[None], thresh=100.0, ctx=ctx)
-                if k == 11:                                  # 121 points, 100 classes alive at once: the 128-class table
-                    assert st[0] == 2                        # does not fit LDS at that size -- reported, not guessed
-                    continue
                 assert st[0] == 0, (k, st)
                 assert h1[0].shape == ((k - 1) ** 2, 2) and np.all(h1[0][:, 0] == 1.0) and np.all(h1[0][:, 1] == r2), k
                 assert len(h0[0]) == k * k and np.all(h0[0][:-1, 1] == 1.0)
-                if (k - 1) ** 2 <= 64:                       # the widest class table a 124-point cloud leaves room for
-                    c0, c1, st = engine.cloud_rips_batch(P[None], normalise=False, thresh=100.0, ctx=ctx)
-                    assert st[0] == 0, (k, st)
-                    assert c1[0].shape == ((k - 1) ** 2, 2) and np.all(c1[0][:, 0] == 1.0) and np.all(c1[0][:, 1] == r2), k
+                c0, c1, st = engine.cloud_rips_batch(P[None], normalise=False, thresh=100.0, ctx=ctx)
+                assert st[0] == 0, (k, st)
+                assert c1[0].shape == ((k - 1) ** 2, 2) and np.all(c1[0][:, 0] == 1.0) and np.all(c1[0][:, 1] == r2), k
+                assert len(c0[0]) == k * k and np.all(c0[0][:-1, 1] == 1.0)
             cube = lattice(2, 3)
             for h1 in (engine.rips_dm_batch(dm(cube)[None], thresh=100.0, ctx=ctx)[1][0],
                        engine.cloud_rips_batch(cube[None], normalise=False, thresh=100.0, ctx=ctx)[1][0]):
@@ -301,9 +299,9 @@ def test_rips_worst_case_class_count_n47(ctx):
     assert st[0] == 0 and _same_multiset(h1[0], o[1])
 
 
-def test_cloud_class_overflow_is_reported_not_silent(ctx):
-    """Point clouds above 112 points have one class word only (LDS); a cloud with more than 64
-    classes alive at once must be FLAGGED, never silently wrong."""
+def test_cloud_with_more_classes_than_lds_holds(ctx):
+    """Point clouds above 112 points have one class word only in LDS; a cloud with more than 64 classes alive at once
+    goes to the last rung of the ladder (class vectors in HBM) and comes back exact -- ripser never refuses a cloud."""
     k = 60
     ang = np.linspace(0, 2 * np.pi, k, endpoint=False)
     a = np.stack([np.cos(ang), np.sin(ang), np.zeros(k)], 1)
@@ -311,10 +309,49 @@ def test_cloud_class_overflow_is_reported_not_silent(ctx):
     pc = np.concatenate([a, b])                      # two rings of 60: a "cylinder" graph, many squares
     h0, h1, st = engine.cloud_rips_batch(pc[None], normalise=False, thresh=0.95, h1_cap=1024, ctx=ctx)
     o = port.rips_f32(port.cloud_dm(pc).astype(np.float32), thresh=0.95)
-    if st[0] == 0:
-        assert _same_multiset(h1[0], o[1])
-    else:
-        assert st[0] & 2
+    assert st[0] == 0
+    assert _same_multiset(h0[0], o[0]) and _same_multiset(h1[0], o[1])
+
+
+def test_last_rung_alone_on_ordinary_windows(ctx):
+    """The pass with the class vectors in HBM is a complete sweep of its own (no chunks, no link argument, no class
+    capacity): forced onto ordinary inputs (TDA_RETRY_LAST_RUNG on windows flagged by hand) it must give what the oracle
+    gives -- audio windows of three bands, EEG-like and white-noise matrices, a tie-heavy metric."""
+    import torch
+    dev = torch.device("cuda", 0)
+    ctx.set_retry_policy(ctx.RETRY_LAST_RUNG)
+    try:
+        for band in ("gamma", "alpha", "delta"):
+            aw = synth.audio_windows(6, band, seed=31)
+            tau = int(engine.tau_batch(aw[:1], 125, ctx=ctx)[0])
+            out = engine.DeviceDiagrams(6, 128, 1024, dev)
+            out.status.fill_(2)
+            engine.takens_rips_dev(torch.from_numpy(aw).to(dev), torch.full((6,), tau, dtype=torch.int32, device=dev), out, ctx=ctx)
+            torch.cuda.synchronize()
+            a0, a1 = out.to_lists()
+            assert int((out.status & ~4).max()) == 0
+            for w in range(6):
+                (o, _) = port.audio_persistence(aw[w], tau)
+                assert _same_multiset(a0[w], o[0]) and _same_multiset(a1[w], o[1]), (band, w)
+        rng = np.random.default_rng(5)
+        mats = [engine.corr_dist_batch(synth.eeg_windows(3, seed=9, kind=k), want_corr=False, ctx=ctx) for k in ("latent", "white")]
+        q = np.round(rng.random((2, 40, 40)) * 6) / 6                      # heavy ties
+        q = (q + q.transpose(0, 2, 1)) / 2
+        for i in range(2):
+            np.fill_diagonal(q[i], 0.0)
+        for d in mats + [q]:
+            n_win, n = d.shape[0], d.shape[1]
+            out = engine.DeviceDiagrams(n_win, n, 1100, dev)
+            out.status.fill_(2)
+            engine.rips_dm_dev(torch.from_numpy(np.ascontiguousarray(d)).to(dev), out, h1_cap=1100, ctx=ctx)
+            torch.cuda.synchronize()
+            a0, a1 = out.to_lists()
+            assert int(out.status.max()) == 0
+            for w in range(n_win):
+                o = port.rips_dm(d[w])
+                assert _same_multiset(a0[w], o[0]) and _same_multiset(a1[w], o[1]), w
+    finally:
+        ctx.set_retry_policy(ctx.RETRY_AUTO)
 
 
 def test_rips_h1_truncation_flag(ctx):
