@@ -77,6 +77,8 @@ def parse_args():
     ap.add_argument("--share-gpu", action="store_true",
                     help="rehearsal only: every rank uses cuda:0 and the all-gather goes through gloo "
                          "(exercises the N>1 code path on a one-GPU box; numbers are meaningless)")
+    ap.add_argument("--dump-rows", default=None, help="rank 0 saves the gathered (n_rec, 5 x 48) result rows of the last "
+                                                      "pass to this .npy file (tests compare N ranks with one)")
     ap.add_argument("--cpu-worker", default=None, help=argparse.SUPPRESS)     # internal: the cpu_baseline child process
     args = ap.parse_args()
     return args
@@ -265,10 +267,15 @@ def main():
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
+    dt_rank = [dt]
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cpu" if args.share_gpu else device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        t = torch.zeros(world, dtype=torch.float64, device="cpu" if args.share_gpu else device)
+        t[rank] = dt
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)          # every rank's own time; the job's time is the slowest rank's
+        dt_rank = [float(x) for x in t.tolist()]
+        dt = max(dt_rank)
+    if args.dump_rows and rank == 0:
+        np.save(args.dump_rows, rows.cpu().numpy())
     sp = spans.cpu().numpy()
     retry_after = retry_ctr.cpu().numpy()
     assert rows.shape == ((n_rec if world > 1 else len(mine)), nb * pipeline.RESULT_COLS)
@@ -282,6 +289,7 @@ def main():
         if rank == 0:
             extras["pcie_inclusive"] = pcie_leg(ctx, device, eeg[nb - 2], aud[nb - 2], wpr)
             extras["front_end_inclusive"] = front_end_leg(ctx, device, args.features_windows)
+            extras["recordings_from_host"] = recordings_leg(ctx, device)
 
     if rank == 0:
         value = total_pairs * args.steps / dt
@@ -319,6 +327,8 @@ def main():
                        "batches_per_pass": n_batches, "windows_per_batch": int(n_win_batch), "thresh": 2.0,
                        "parallelism": f"recordings dealt over {world} rank(s), one all-gather per pass",
                        "batches_in_flight": lanes.depth, "hip_graph": lanes.graph,
+                       "ms_per_step_per_rank": [round(x / args.steps * 1e3, 4) for x in dt_rank],
+                       "allgather_ms": runner.allgather_ms(),
                        "first_pass_class_bits": {"eeg": 64 * cw_dm, "audio": 32 * cw_cloud if cw_cloud == 1 else 64},
                        "windows_repaired": {"eeg": int(retry_after[0] - retry_before[0]),
                                             "audio": int(retry_after[1] - retry_before[1]),
@@ -511,6 +521,41 @@ def front_end_leg(ctx, device, n_sel, n_rec=354, n_samples=4606):
             "sample": f"{n_rec} recordings x 47 channels x {n_samples} samples ({raw_h.numel() * 8 / 1e6:.0f} MB uploaded per step), "
                       f"{n_sel} of {per_rec} windows per recording-band = {n_win} windows",
             "matrix_finite": bool(torch.isfinite(out_h).all().item()), "windows_bad_status": bad}
+
+
+def recordings_leg(ctx, device, n_rec=708, shard=236, n_samples=4606):
+    """process_recording whole, from HOST memory (never `value`): raw EEG (47 x 4,606 float64 = 71 windows) and the 250 Hz
+    audio envelope of every recording in pinned host buffers -> per shard: upload, five zero-phase band-passes of both,
+    the 15 selected windows per recording-band read in place -> corr -> dist -> Rips | tau -> Takens -> Rips ->
+    Wasserstein -> rows -> back to the host; the upload of shard k + 1 overlaps the compute of shard k
+    (recordings.RecordingPass).  Half of the corpus' recordings per run, twice."""
+    import torch
+    from tda_eeg_audio_amd import recordings
+    g = torch.Generator(device="cpu")
+    g.manual_seed(909)
+    raw_h = torch.randn((n_rec, 47, n_samples), generator=g, dtype=torch.float64)
+    raw_h += 0.5 * torch.randn((n_rec, 1, n_samples), generator=g, dtype=torch.float64)
+    raw_h = raw_h.pin_memory()
+    env_h = (torch.randn((n_rec, n_samples), generator=g, dtype=torch.float64).abs()
+             + 0.3 * torch.randn((n_rec, n_samples), generator=g, dtype=torch.float64).cumsum(1).abs() * 0.02).pin_memory()
+    rp = recordings.RecordingPass(n_samples, shard, device, ctx=ctx)
+    rows = rp.run(raw_h, env_h)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    K = 2
+    for _ in range(K):
+        rows = rp.run(raw_h, env_h, rows)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / K
+    n_pairs = n_rec * 5 * rp.k
+    nbytes = raw_h.numel() * 8 + env_h.numel() * 8
+    return {"value": n_pairs / dt, "unit": "window pairs/s", "ms_per_run": dt * 1e3, "h2d_GBps": nbytes / dt / 1e9,
+            "stage": "pinned raw EEG + 250 Hz envelope -> h2d -> 5 x (sosfiltfilt of all channels + filtfilt of the envelopes) "
+                     "-> fused EEG window kernel on sliding windows + tau / Takens / Rips on the selected envelope windows "
+                     "-> finish -> Wasserstein H0 / H1 -> rows -> d2h; shards double-buffered, one stream per band",
+            "sample": f"{n_rec} recordings x 47 channels x {n_samples} samples + envelopes ({nbytes / 1e6:.0f} MB uploaded per "
+                      f"run) in shards of {shard}; {rp.k} of {rp.per_rec} windows per recording-band = {n_pairs} window pairs",
+            "rows_finite": bool(torch.isfinite(rows).all().item()), "band_steps_rerun_with_full_ladder": rp.repairs}
 
 
 # ------------------------------------------------------------------------------------------------------------

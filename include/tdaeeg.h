@@ -223,6 +223,18 @@ tda_status tda_filtfilt_dev(tda_ctx* ctx, const double* x, int n_sig, int n_samp
 tda_status tda_filtfilt(tda_ctx* ctx, const double* x, int n_sig, int n_samples, const double* b,
                         const double* a, const double* zi, int ntaps, int edge, double* y);
 
+/* Filter BANKS: the same n_sig signals through n_filters filters of equal structure in ONE launch -- the five frequency
+ * bands of apply_bandpass_filter (nb1:236-263, one call per band in preprocess_file nb1:388-494) and of bandpass_filter
+ * (utils.py:66-74, one call per band in process_recording, cmp:63-64).  sos (n_filters, n_sections, 6), zi (n_filters,
+ * n_sections, 2) / b, a (n_filters, ntaps), zi (n_filters, ntaps-1): HOST pointers; y (n_filters, n_sig, n_samples),
+ * work (n_filters, n_sig, n_samples + 2*edge): device.  n_filters <= 5.  Bit-identical to the single-filter calls. */
+tda_status tda_sosfiltfilt_bank_dev(tda_ctx* ctx, const double* x, int n_sig, int n_samples, const double* sos,
+                                    const double* zi, int n_filters, int n_sections, int edge, double* y, double* work,
+                                    void* stream);
+tda_status tda_filtfilt_bank_dev(tda_ctx* ctx, const double* x, int n_sig, int n_samples, const double* b,
+                                 const double* a, const double* zi, int n_filters, int ntaps, int edge, double* y,
+                                 double* work, void* stream);
+
 /* Audio front end.  tda_upfirdn replaces scipy.signal.resample_poly(audio, 250, 44100) (scripts/utils.py:77-79):
  * h (len_h, host-designed exactly as scipy does, incl. its zero padding and the factor `up`),
  *   y[j] = sum_i x[i] * h[(j + n_pre_remove)*down - i*up],  j < n_out.

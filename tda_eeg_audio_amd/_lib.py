@@ -55,6 +55,8 @@ SYMBOLS = {
     "tda_sosfiltfilt": (_I, [c_vp, c_vp, _I, _I, c_vp, c_vp, _I, _I, c_vp]),
     "tda_filtfilt_dev": (_I, [c_vp, c_vp, _I, _I, c_vp, c_vp, c_vp, _I, _I, c_vp, c_vp, c_vp]),
     "tda_filtfilt": (_I, [c_vp, c_vp, _I, _I, c_vp, c_vp, c_vp, _I, _I, c_vp]),
+    "tda_sosfiltfilt_bank_dev": (_I, [c_vp, c_vp, _I, _I, c_vp, c_vp, _I, _I, _I, c_vp, c_vp, c_vp]),
+    "tda_filtfilt_bank_dev": (_I, [c_vp, c_vp, _I, _I, c_vp, c_vp, c_vp, _I, _I, _I, c_vp, c_vp, c_vp]),
     "tda_upfirdn_dev": (_I, [c_vp, c_vp, C.c_longlong, c_vp, _I, _I, _I, C.c_longlong, C.c_longlong, c_vp, c_vp]),
     "tda_upfirdn": (_I, [c_vp, c_vp, C.c_longlong, c_vp, _I, _I, _I, C.c_longlong, C.c_longlong, c_vp]),
     "tda_hilbert_envelope_dev": (_I, [c_vp, c_vp, _I, c_vp, c_vp, c_vp]),

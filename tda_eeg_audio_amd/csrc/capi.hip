@@ -207,6 +207,25 @@ tda_status tda_filtfilt_dev(tda_ctx* ctx, const double* x, int n_sig, int n_samp
     return launch_filtfilt(ctx, x, n_sig, n_samples, b, a, zi, ntaps, edge, y, work, (hipStream_t)stream);
 }
 
+tda_status tda_sosfiltfilt_bank_dev(tda_ctx* ctx, const double* x, int n_sig, int n_samples, const double* sos,
+                                    const double* zi, int n_filters, int n_sections, int edge, double* y, double* work,
+                                    void* stream)
+{
+    CHECK_CTX(ctx); CHECK_NONNEG(ctx, n_sig);
+    if (n_sig) { CHECK_PTR(ctx, x); CHECK_PTR(ctx, y); CHECK_PTR(ctx, work); }
+    CHECK_PTR(ctx, sos); CHECK_PTR(ctx, zi);
+    return launch_sosfiltfilt(ctx, x, n_sig, n_samples, sos, zi, n_sections, edge, y, work, (hipStream_t)stream, n_filters);
+}
+
+tda_status tda_filtfilt_bank_dev(tda_ctx* ctx, const double* x, int n_sig, int n_samples, const double* b, const double* a,
+                                 const double* zi, int n_filters, int ntaps, int edge, double* y, double* work, void* stream)
+{
+    CHECK_CTX(ctx); CHECK_NONNEG(ctx, n_sig);
+    if (n_sig) { CHECK_PTR(ctx, x); CHECK_PTR(ctx, y); CHECK_PTR(ctx, work); }
+    CHECK_PTR(ctx, b); CHECK_PTR(ctx, a); CHECK_PTR(ctx, zi);
+    return launch_filtfilt(ctx, x, n_sig, n_samples, b, a, zi, ntaps, edge, y, work, (hipStream_t)stream, n_filters);
+}
+
 tda_status tda_upfirdn_dev(tda_ctx* ctx, const double* x, long long n_in, const double* h, int len_h, int up, int down,
                            long long n_pre_remove, long long n_out, double* y, void* stream)
 {

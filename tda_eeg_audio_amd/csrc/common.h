@@ -156,9 +156,9 @@ tda_status launch_rips_cloud(tda_ctx*, const double* win_or_pc, const int* tau_o
                              int dim, int subsample, int mode, int normalise, double thresh, double*, int, int*,
                              double*, int, int*, int* n_points, int*, hipStream_t);
 tda_status launch_sosfiltfilt(tda_ctx*, const double*, int, int, const double*, const double*, int, int, double*, double*,
-                              hipStream_t);
+                              hipStream_t, int n_filt = 1);
 tda_status launch_filtfilt(tda_ctx*, const double*, int, int, const double*, const double*, const double*, int, int, double*,
-                           double*, hipStream_t);
+                           double*, hipStream_t, int n_filt = 1);
 tda_status launch_upfirdn(tda_ctx*, const double*, long long, const double*, int, int, int, long long, long long, double*,
                           hipStream_t);
 tda_status launch_hilbert_env(tda_ctx*, const double*, int, const double*, double*, hipStream_t);

@@ -34,6 +34,12 @@ struct BaParams {
     double zi[F_MAX_TAPS];                 // lfilter_zi, length ntaps-1
     int ntaps;
 };
+// A BANK of filters over the same signals (the five frequency bands of the path): blockIdx.y picks the filter, the
+// outputs of filter f lie behind those of filter f - 1.  One launch instead of five -- the recursions are chains of
+// dependent operations on few waves, and five times the waves cost (almost) no more time.
+#define F_MAX_BANK 5
+struct SosBank { SosParams f[F_MAX_BANK]; };
+struct BaBank { BaParams f[F_MAX_BANK]; };
 
 // odd extension (scipy.signal._arraytools.odd_ext): index i of the padded signal, N = L + 2*edge
 __device__ __forceinline__ double odd_ext_at(const double* __restrict__ x, int L, int edge, int i)
@@ -88,24 +94,35 @@ struct BaFilter {
     }
 };
 
-template <class FILT, class PARAMS>
+template <class FILT, class BANK>
 __global__ void __launch_bounds__(FT)
-zero_phase_kernel(const double* __restrict__ x, int n_sig, int L, int edge, PARAMS p, double* __restrict__ y,
+zero_phase_kernel(const double* __restrict__ x, int n_sig, int L, int edge, BANK bank, double* __restrict__ y,
                   double* __restrict__ work)
 {
     __shared__ double tile[FT * FTP];
+    const auto& p = bank.f[blockIdx.y];
     const int lane = threadIdx.x;
     const int s0 = blockIdx.x * FT;
     const int sig = s0 + lane;
     const int N = L + 2 * edge;
+    y += (size_t)blockIdx.y * n_sig * L;
+    work += (size_t)blockIdx.y * n_sig * N;
     const bool live = sig < n_sig;
     FILT f;
     // ---- forward over the odd extension, output to work (n_sig, N) ----
     for (int c0 = 0; c0 < N; c0 += FT) {
         const int cn = (N - c0) < FT ? (N - c0) : FT;
         // load rows s0..s0+63, samples c0..c0+cn: lane = sample (coalesced along the row)
-        for (int r = 0; r < FT; ++r)
-            if (s0 + r < n_sig && lane < cn) tile[r * FTP + lane] = odd_ext_at(x + (size_t)(s0 + r) * L, L, edge, c0 + lane);
+        // (sixteen rows per trip, all loads issued before the first one is used: one load latency per trip instead of
+        // one per row -- the kernel is a chain of dependent trips on very few waves)
+        for (int r0 = 0; r0 < FT; r0 += 16) {
+            double v[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                v[r] = (s0 + r0 + r < n_sig && lane < cn) ? odd_ext_at(x + (size_t)(s0 + r0 + r) * L, L, edge, c0 + lane) : 0.0;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) tile[(r0 + r) * FTP + lane] = v[r];
+        }
         __syncthreads();
         if (live) {
             if (c0 == 0) f.init(p, tile[lane * FTP]);
@@ -120,8 +137,14 @@ zero_phase_kernel(const double* __restrict__ x, int n_sig, int L, int edge, PARA
     for (int c1 = N; c1 > 0; c1 -= FT) {
         const int c0 = c1 - FT > 0 ? c1 - FT : 0;
         const int cn = c1 - c0;
-        for (int r = 0; r < FT; ++r)
-            if (s0 + r < n_sig && lane < cn) tile[r * FTP + lane] = work[(size_t)(s0 + r) * N + c0 + lane];
+        for (int r0 = 0; r0 < FT; r0 += 16) {
+            double v[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                v[r] = (s0 + r0 + r < n_sig && lane < cn) ? work[(size_t)(s0 + r0 + r) * N + c0 + lane] : 0.0;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) tile[(r0 + r) * FTP + lane] = v[r];
+        }
         __syncthreads();
         if (live) {
             if (c1 == N) f.init(p, tile[lane * FTP + cn - 1]);       // zi * y[-1]
@@ -154,15 +177,18 @@ __device__ __forceinline__ double dpp_row_shr1_f64(double v)
 
 template <int LPS>
 __global__ void __launch_bounds__(64)
-sos_pipe_kernel(const double* __restrict__ x, int n_sig, int L, int edge, SosParams p, double* __restrict__ y,
+sos_pipe_kernel(const double* __restrict__ x, int n_sig, int L, int edge, SosBank bank, double* __restrict__ y,
                 double* __restrict__ work)
 {
     constexpr int SPW = 64 / LPS;                      // signals per wave
     __shared__ double tin[SPW * FTP], tout[SPW * FTP];
     __shared__ double coef[F_MAX_SEC][8];              // b0 b1 b2 a0 a1 a2 zi0 zi1 per section (identity beyond n_sec)
+    const SosParams& p = bank.f[blockIdx.y];
     const int lane = threadIdx.x, sl = lane / LPS, s = lane % LPS;
     const int s0 = blockIdx.x * SPW, sig = s0 + sl;
     const int N = L + 2 * edge;
+    y += (size_t)blockIdx.y * n_sig * L;
+    work += (size_t)blockIdx.y * n_sig * N;
     const bool live = sig < n_sig;
     if (lane < F_MAX_SEC * 8) {
         const int q = lane >> 3, k = lane & 7;
@@ -181,12 +207,17 @@ sos_pipe_kernel(const double* __restrict__ x, int n_sig, int L, int edge, SosPar
         double outp = 0.0;                              // this lane's output of the previous step
         for (int c0 = 0; c0 < N + LPS - 1; c0 += FT) {
             // input chunk: positions c0 .. c0+63 of the pass (lane = position: coalesced rows)
-            for (int r = 0; r < SPW; ++r) {
+            {   // (all rows' loads in flight before the first is used: one load latency per chunk instead of SPW)
                 const int j = c0 + lane;
-                double v = 0.0;
-                if (s0 + r < n_sig && j < N)
-                    v = pass == 0 ? odd_ext_at(x + (size_t)(s0 + r) * L, L, edge, j) : work[(size_t)(s0 + r) * N + (N - 1 - j)];
-                tin[r * FTP + lane] = v;
+                double v[SPW];
+#pragma unroll
+                for (int r = 0; r < SPW; ++r) {
+                    v[r] = 0.0;
+                    if (s0 + r < n_sig && j < N)
+                        v[r] = pass == 0 ? odd_ext_at(x + (size_t)(s0 + r) * L, L, edge, j) : work[(size_t)(s0 + r) * N + (N - 1 - j)];
+                }
+#pragma unroll
+                for (int r = 0; r < SPW; ++r) tin[r * FTP + lane] = v[r];
             }
             __syncthreads();
             for (int t = 0; t < FT; ++t) {
@@ -222,46 +253,54 @@ sos_pipe_kernel(const double* __restrict__ x, int n_sig, int L, int edge, SosPar
 }
 
 tda_status launch_sosfiltfilt(tda_ctx* ctx, const double* x, int n_sig, int L, const double* sos, const double* zi,
-                              int n_sec, int edge, double* y, double* work, hipStream_t st)
+                              int n_sec, int edge, double* y, double* work, hipStream_t st, int n_filt)
 {
-    if (n_sig == 0) return TDA_OK;
+    if (n_sig == 0 || n_filt == 0) return TDA_OK;
     if (n_sec < 1 || n_sec > F_MAX_SEC) TDA_FAIL(ctx, TDA_ERR_UNSUPPORTED, "n_sections must be in [1,8]");
+    if (n_filt < 1 || n_filt > F_MAX_BANK) TDA_FAIL(ctx, TDA_ERR_UNSUPPORTED, "a filter bank holds 1..5 filters");
     if (edge < 0 || L <= edge) TDA_FAIL(ctx, TDA_ERR_INVALID, "signal length must exceed the pad length");   // scipy raises too
-    SosParams p = {};
-    p.n_sec = n_sec;
-    for (int s = 0; s < n_sec; ++s) {
-        for (int k = 0; k < 6; ++k) p.c[s][k] = sos[s * 6 + k];
-        p.zi[s][0] = zi[s * 2]; p.zi[s][1] = zi[s * 2 + 1];
+    SosBank bank = {};
+    for (int f = 0; f < n_filt; ++f) {
+        SosParams& p = bank.f[f];
+        p.n_sec = n_sec;
+        for (int s = 0; s < n_sec; ++s) {
+            for (int k = 0; k < 6; ++k) p.c[s][k] = sos[(f * n_sec + s) * 6 + k];
+            p.zi[s][0] = zi[(f * n_sec + s) * 2]; p.zi[s][1] = zi[(f * n_sec + s) * 2 + 1];
+        }
     }
     // sections pipelined across lanes (bit-identical; see sos_pipe_kernel).  TDA_SOS_SERIAL=1: the one-lane-per-signal
     // form, kept for measurements
     static const bool serial = getenv("TDA_SOS_SERIAL") != nullptr;
     if (serial)
-        hipLaunchKernelGGL((zero_phase_kernel<SosFilter, SosParams>), dim3((n_sig + FT - 1) / FT), dim3(FT), 0, st, x, n_sig,
-                           L, edge, p, y, work);
+        hipLaunchKernelGGL((zero_phase_kernel<SosFilter, SosBank>), dim3((n_sig + FT - 1) / FT, n_filt), dim3(FT), 0, st, x, n_sig,
+                           L, edge, bank, y, work);
     else if (n_sec <= 2)
-        hipLaunchKernelGGL(sos_pipe_kernel<2>, dim3((n_sig + 31) / 32), dim3(64), 0, st, x, n_sig, L, edge, p, y, work);
+        hipLaunchKernelGGL(sos_pipe_kernel<2>, dim3((n_sig + 31) / 32, n_filt), dim3(64), 0, st, x, n_sig, L, edge, bank, y, work);
     else if (n_sec <= 4)
-        hipLaunchKernelGGL(sos_pipe_kernel<4>, dim3((n_sig + 15) / 16), dim3(64), 0, st, x, n_sig, L, edge, p, y, work);
+        hipLaunchKernelGGL(sos_pipe_kernel<4>, dim3((n_sig + 15) / 16, n_filt), dim3(64), 0, st, x, n_sig, L, edge, bank, y, work);
     else
-        hipLaunchKernelGGL(sos_pipe_kernel<8>, dim3((n_sig + 7) / 8), dim3(64), 0, st, x, n_sig, L, edge, p, y, work);
+        hipLaunchKernelGGL(sos_pipe_kernel<8>, dim3((n_sig + 7) / 8, n_filt), dim3(64), 0, st, x, n_sig, L, edge, bank, y, work);
     TDA_HIP(ctx, hipGetLastError());
     return TDA_OK;
 }
 
 tda_status launch_filtfilt(tda_ctx* ctx, const double* x, int n_sig, int L, const double* b, const double* a,
-                           const double* zi, int ntaps, int edge, double* y, double* work, hipStream_t st)
+                           const double* zi, int ntaps, int edge, double* y, double* work, hipStream_t st, int n_filt)
 {
-    if (n_sig == 0) return TDA_OK;
+    if (n_sig == 0 || n_filt == 0) return TDA_OK;
     if (ntaps < 2 || ntaps > F_MAX_TAPS) TDA_FAIL(ctx, TDA_ERR_UNSUPPORTED, "len(b)=len(a) must be in [2,17]");
+    if (n_filt < 1 || n_filt > F_MAX_BANK) TDA_FAIL(ctx, TDA_ERR_UNSUPPORTED, "a filter bank holds 1..5 filters");
     if (edge < 0 || L <= edge) TDA_FAIL(ctx, TDA_ERR_INVALID, "signal length must exceed the pad length");
-    BaParams p;
-    p.ntaps = ntaps;
-    const double a0 = a[0];
-    for (int k = 0; k < F_MAX_TAPS; ++k) { p.b[k] = k < ntaps ? b[k] / a0 : 0.0; p.a[k] = k < ntaps ? a[k] / a0 : 0.0; }
-    for (int k = 0; k < F_MAX_TAPS; ++k) p.zi[k] = k < ntaps - 1 ? zi[k] : 0.0;
-    hipLaunchKernelGGL((zero_phase_kernel<BaFilter, BaParams>), dim3((n_sig + FT - 1) / FT), dim3(FT), 0, st, x, n_sig,
-                       L, edge, p, y, work);
+    BaBank bank = {};
+    for (int f = 0; f < n_filt; ++f) {
+        BaParams& p = bank.f[f];
+        p.ntaps = ntaps;
+        const double a0 = a[f * ntaps];
+        for (int k = 0; k < F_MAX_TAPS; ++k) { p.b[k] = k < ntaps ? b[f * ntaps + k] / a0 : 0.0; p.a[k] = k < ntaps ? a[f * ntaps + k] / a0 : 0.0; }
+        for (int k = 0; k < F_MAX_TAPS; ++k) p.zi[k] = k < ntaps - 1 ? zi[f * (ntaps - 1) + k] : 0.0;
+    }
+    hipLaunchKernelGGL((zero_phase_kernel<BaFilter, BaBank>), dim3((n_sig + FT - 1) / FT, n_filt), dim3(FT), 0, st, x, n_sig,
+                       L, edge, bank, y, work);
     TDA_HIP(ctx, hipGetLastError());
     return TDA_OK;
 }

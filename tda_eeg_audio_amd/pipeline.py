@@ -54,9 +54,12 @@ class Workspace:
         self.dist = None if self.fused else torch.empty((n_win, n_ch, n_ch), **f64)
 
 
-def run_step(eeg_win, audio_win, ws, ctx=None, max_lag=125, timers=None, retry="auto"):
+def run_step(eeg_win, audio_win, ws, ctx=None, max_lag=125, timers=None, retry="auto", eeg_sliding=None):
     """One pass of the hot path over the batch.  eeg_win (n_win,47,250) f64, audio_win (n_win,250)
-    f64, both resident in HBM.  Returns ws.result (n_seg, 48).  `timers`: optional dict of
+    f64, both resident in HBM.  Returns ws.result (n_seg, 48).
+    eeg_sliding = (sig_t (n_rec, 47, L), win_len, step, sel_t): the EEG windows are read IN PLACE from band-passed
+    recordings instead (window sel_t[i] = r * n_win_per_rec + k; eeg_win is ignored) -- recordings.RecordingPass.
+    `timers`: optional dict of
     (start,end) torch.cuda.Event pairs per stage, recorded on the launch stream.
     retry="auto": every Rips call launches its widening passes (exact by itself).  retry="first": first passes
     only; retry="one": first passes plus ONE widening pass each (TDA_RETRY_ONE_STEP: the wide rungs of the ladder
@@ -70,14 +73,14 @@ def run_step(eeg_win, audio_win, ws, ctx=None, max_lag=125, timers=None, retry="
         ctx.set_retry_policy(ctx.RETRY_FIRST_PASS if retry == "first" else ctx.RETRY_ONE_STEP)
     ctx.set_h1_order(ctx.ORDER_DEFERRED)         # one finishing pass for the three diagram sets of the batch
     try:
-        return _run_step(eeg_win, audio_win, ws, ctx, max_lag, timers, retry)
+        return _run_step(eeg_win, audio_win, ws, ctx, max_lag, timers, retry, eeg_sliding)
     finally:
         ctx.set_h1_order(ctx.ORDER_IN_CALL)
         if retry != "auto":
             ctx.set_retry_policy(ctx.RETRY_AUTO)
 
 
-def _run_step(eeg_win, audio_win, ws, ctx, max_lag, timers, retry):
+def _run_step(eeg_win, audio_win, ws, ctx, max_lag, timers, retry, eeg_sliding=None):
     import torch
 
     def stage(name, fn):
@@ -97,7 +100,10 @@ def _run_step(eeg_win, audio_win, ws, ctx, max_lag, timers, retry):
     if ws.overlap:
         side.wait_stream(main)
     with torch.cuda.stream(side):
-        if ws.fused and eeg_win.shape[2] <= 256:
+        if eeg_sliding is not None:
+            sig_t, win_len, step, sel_t = eeg_sliding
+            stage("eeg_window", lambda: engine.eeg_window_sliding_dev(sig_t, win_len, step, sel_t=sel_t, out=ws.eeg, ctx=ctx))
+        elif ws.fused and eeg_win.shape[2] <= 256:
             stage("eeg_window", lambda: engine.eeg_window_dev(eeg_win, ws.eeg, ctx=ctx))
         else:
             if ws.dist is None:
@@ -305,6 +311,7 @@ class CorpusPass:
         self.passes = 0
         self.gathered = None
         self._open = {}
+        self._gather_events = []
 
     def _post(self, k, i, result):
         """Runs on the lane's stream when batch i of pass k has been verified: its rows join the pass' block; the
@@ -329,7 +336,11 @@ class CorpusPass:
             flat = blk.view(self.n_rec, self.n_bands * RESULT_COLS)
             if self.gather:
                 from . import dist as tdist
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
                 self.gathered = tdist.all_gather_rows(flat, self.my_recs, self.shards, self.n_total)
+                e1.record()
+                self._gather_events = (self._gather_events + [(e0, e1)])[-16:]
             else:
                 self.gathered = flat.clone() if len(self.batches) == 1 else flat
         return None
@@ -352,6 +363,14 @@ class CorpusPass:
         for _ in range(self.lanes.depth if len(self.batches) == 1 else 1):
             self.step()
         return self.finish()
+
+    def allgather_ms(self):
+        """Mean duration of the all-gather of a pass (events on the lane's stream), None on one rank."""
+        import torch
+        if not self._gather_events:
+            return None
+        torch.cuda.synchronize()
+        return round(float(np.mean([a.elapsed_time(b) for a, b in self._gather_events])), 4)
 
     def finish(self):
         """Verify and publish everything in flight; returns the rows of the last pass:

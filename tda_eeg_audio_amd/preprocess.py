@@ -174,6 +174,79 @@ def recordings_to_features(raw_t, fs, sel_t=None, n_sel_per_rec=None, freq_bands
     return X.view(n_rec, len(freq_bands) * 44), status
 
 
+def filtfilt_dev(x_t, b, a, y_t=None, work_t=None, ctx=None):
+    """scipy.signal.filtfilt(b, a, x, axis=-1) on device tensors: x_t (n_sig, n_samples) float64, one launch (the band-pass
+    of the audio envelope, utils.py:66-74, for every recording of a shard at once)."""
+    import torch
+    ctx = ctx or get_ctx()
+    assert x_t.is_cuda and x_t.dtype == torch.float64 and x_t.is_contiguous() and x_t.dim() == 2
+    b = np.ascontiguousarray(np.atleast_1d(b), dtype=np.float64)
+    a = np.ascontiguousarray(np.atleast_1d(a), dtype=np.float64)
+    ntaps = max(len(a), len(b))
+    b = np.concatenate([b, np.zeros(ntaps - len(b))]); a = np.concatenate([a, np.zeros(ntaps - len(a))])
+    zi = np.ascontiguousarray(signal.lfilter_zi(b, a))
+    edge = 3 * ntaps
+    n_sig, n_s = x_t.shape
+    if n_s <= edge:
+        raise ValueError(f"The length of the input vector x must be greater than padlen, which is {edge}.")
+    if y_t is None:
+        y_t = torch.empty_like(x_t)
+    if work_t is None or work_t.numel() < n_sig * (n_s + 2 * edge):
+        work_t = torch.empty((n_sig, n_s + 2 * edge), dtype=torch.float64, device=x_t.device)
+    ctx.check(ctx.lib.tda_filtfilt_dev(ctx.h, C.c_void_p(x_t.data_ptr()), n_sig, n_s, ptr(b), ptr(a), ptr(zi), ntaps, edge,
+                                       C.c_void_p(y_t.data_ptr()), C.c_void_p(work_t.data_ptr()),
+                                       C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    return y_t
+
+
+def bandpass_bank_dev(x_t, bands, fs, order=FILTER_ORDER, y_t=None, work_t=None, ctx=None):
+    """apply_bandpass_filter (nb1:236-263) for ALL bands in one launch: x_t (n_sig, n_samples) -> y_t (n_bands, n_sig,
+    n_samples), bit-identical to one bandpass_dev call per band.  bands: iterable of (lowcut, highcut)."""
+    import torch
+    ctx = ctx or get_ctx()
+    assert x_t.is_cuda and x_t.dtype == torch.float64 and x_t.is_contiguous() and x_t.dim() == 2
+    n_sig, n_s = x_t.shape
+    plans = [_sos_plan(design_bandpass_filter(lo, hi, fs, order)) for lo, hi in bands]
+    nf, n_sec, edge = len(plans), plans[0][0].shape[0], plans[0][2]
+    assert all(p[0].shape[0] == n_sec and p[2] == edge for p in plans), "the filters of a bank share their structure"
+    if n_s <= edge:
+        raise ValueError(f"The length of the input vector x must be greater than padlen, which is {edge}.")
+    sos = np.ascontiguousarray(np.stack([p[0] for p in plans])); zi = np.ascontiguousarray(np.stack([p[1] for p in plans]))
+    if y_t is None:
+        y_t = torch.empty((nf, n_sig, n_s), dtype=torch.float64, device=x_t.device)
+    if work_t is None or work_t.numel() < nf * n_sig * (n_s + 2 * edge):
+        work_t = torch.empty((nf, n_sig, n_s + 2 * edge), dtype=torch.float64, device=x_t.device)
+    ctx.check(ctx.lib.tda_sosfiltfilt_bank_dev(ctx.h, C.c_void_p(x_t.data_ptr()), n_sig, n_s, ptr(sos), ptr(zi), nf, n_sec, edge,
+                                               C.c_void_p(y_t.data_ptr()), C.c_void_p(work_t.data_ptr()),
+                                               C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    return y_t
+
+
+def filtfilt_bank_dev(x_t, bas, y_t=None, work_t=None, ctx=None):
+    """scipy.signal.filtfilt for a bank of (b, a) pairs of equal length in one launch: x_t (n_sig, n_samples) -> y_t
+    (n_filters, n_sig, n_samples) -- bandpass_filter (utils.py:66-74) of the audio envelope for all bands (cmp:63-64)."""
+    import torch
+    ctx = ctx or get_ctx()
+    assert x_t.is_cuda and x_t.dtype == torch.float64 and x_t.is_contiguous() and x_t.dim() == 2
+    n_sig, n_s = x_t.shape
+    ntaps = max(max(len(b), len(a)) for b, a in bas)
+    B = np.zeros((len(bas), ntaps)); A = np.zeros((len(bas), ntaps)); Z = np.zeros((len(bas), ntaps - 1))
+    for f, (b, a) in enumerate(bas):
+        B[f, :len(b)] = b; A[f, :len(a)] = a
+        Z[f] = signal.lfilter_zi(B[f], A[f])
+    edge = 3 * ntaps
+    if n_s <= edge:
+        raise ValueError(f"The length of the input vector x must be greater than padlen, which is {edge}.")
+    if y_t is None:
+        y_t = torch.empty((len(bas), n_sig, n_s), dtype=torch.float64, device=x_t.device)
+    if work_t is None or work_t.numel() < len(bas) * n_sig * (n_s + 2 * edge):
+        work_t = torch.empty((len(bas), n_sig, n_s + 2 * edge), dtype=torch.float64, device=x_t.device)
+    ctx.check(ctx.lib.tda_filtfilt_bank_dev(ctx.h, C.c_void_p(x_t.data_ptr()), n_sig, n_s, ptr(B), ptr(A), ptr(Z), len(bas), ntaps,
+                                            edge, C.c_void_p(y_t.data_ptr()), C.c_void_p(work_t.data_ptr()),
+                                            C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    return y_t
+
+
 def eeg_to_distances(eeg, fs, freq_bands=FREQ_BANDS, window_size=WINDOW_SIZE_SEC, overlap=OVERLAP_PERCENT,
                      order=FILTER_ORDER, want_corr=False, ctx=None):
     """raw EEG (n_ch, n_samples) -> {band: (n_win, n_ch, n_ch) distance matrices}; everything between the

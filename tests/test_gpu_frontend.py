@@ -128,3 +128,42 @@ def test_fused_sliding_windows_equal_stacked_windows(ctx):
         r, k = divmod(g, per_rec)
         o = port.rips_dm(port.corr_dist(filt[r][:, k * 62:k * 62 + 250])[1])
         assert np.array_equal(brute.sort_rows(f0[g]), brute.sort_rows(o[0])) and np.array_equal(brute.sort_rows(f1[g]), brute.sort_rows(o[1]))
+
+
+def test_recording_pass_equals_stacked_windows(ctx):
+    """process_recording whole, from host memory (recordings.RecordingPass: upload -> band-passes of EEG and envelope ->
+    windows read in place -> tau / Takens / Rips / Wasserstein / rows -> host), shards of 3 with a short last shard,
+    against (a) pipeline.run_step on the STACKED selected windows of the same band-passed signals (bit for bit) and
+    (b) scipy's filters + the CPU oracle end to end for one recording-band."""
+    import torch
+    from oracle import pipeline_ref
+    from tda_eeg_audio_amd import pipeline, preprocess, recordings, utils
+    dev = torch.device("cuda", ctx.device)
+    rng = np.random.default_rng(33)
+    n_rec, L = 7, 1500
+    raw = rng.standard_normal((n_rec, 47, L)) + 0.5 * rng.standard_normal((n_rec, 1, L))
+    env = np.abs(rng.standard_normal((n_rec, L))).cumsum(axis=1) * 0.01 + np.abs(rng.standard_normal((n_rec, L)))
+    rp = recordings.RecordingPass(L, 3, dev, ctx=ctx)
+    rows = rp.run(torch.from_numpy(raw).pin_memory(), torch.from_numpy(env).pin_memory()).numpy()
+    assert rows.shape == (n_rec, 5, 48) and np.isfinite(rows).all()
+    per_rec = (L - 250) // 62 + 1
+    pick = recordings.select_windows(per_rec)
+    assert np.array_equal(pick, np.linspace(0, per_rec - 1, 15, dtype=int))
+    seg_off = np.arange(0, n_rec * 15 + 1, 15, dtype=np.int32)
+    ws = pipeline.Workspace(n_rec * 15, seg_off, dev)
+    for b, (name, (lo, hi)) in enumerate(preprocess.FREQ_BANDS.items()):
+        y = preprocess.apply_bandpass_filter(raw.reshape(n_rec * 47, L), lo, hi, 250).reshape(n_rec, 47, L)
+        ya = np.stack([preprocess.bandpass_filter(env[r], 250, lo, hi) for r in range(n_rec)])
+        eeg = np.stack([y[r][:, k * 62:k * 62 + 250] for r in range(n_rec) for k in pick])
+        aud = np.stack([utils.create_windows(ya[r], 250, 62)[k] for r in range(n_rec) for k in pick])
+        ref = pipeline.run_step(torch.from_numpy(eeg).to(dev), torch.from_numpy(aud).to(dev), ws, ctx=ctx).cpu().numpy()
+        assert np.array_equal(rows[:, b], ref, equal_nan=True), name
+        if name == "alpha":                     # scipy + oracle, one recording
+            ys = signal.sosfiltfilt(preprocess.design_bandpass_filter(lo, hi, 250), raw[2], axis=-1)
+            bb, aa = signal.butter(4, [lo / 125, hi / 125], btype="band")
+            yas = signal.filtfilt(bb, aa, env[2])
+            e1 = np.stack([ys[:, k * 62:k * 62 + 250] for k in pick])
+            a1 = np.stack([yas[k * 62:k * 62 + 250] for k in pick])
+            o = pipeline_ref.reference_step_cpu(e1, a1, np.array([0, 15], np.int32))
+            assert np.abs(rows[2, b, :2] - o[0, :2]).max() < 1e-6 and np.array_equal(rows[2, b, 2:4], o[0, 2:4])
+            assert np.allclose(rows[2, b, 4:], o[0, 4:], rtol=1e-9, atol=1e-12)

@@ -191,7 +191,7 @@ def test_bench_two_rank_rehearsal_and_corpus_rows(tmp_path):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--share-gpu", "--recordings", "36", "--steps", "2",
-           "--warmup", "1", "--no-cpu", "--features-steps", "1"]
+           "--warmup", "1", "--no-cpu", "--features-steps", "1", "--dump-rows", str(tmp_path / "rows2.npy")]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
@@ -202,3 +202,34 @@ def test_bench_two_rank_rehearsal_and_corpus_rows(tmp_path):
     assert d["config"]["result_rows_finite_frac"] == 1.0
     assert d["features_pass"]["matrix_shape"] == [36, 220] and d["features_pass"]["matrix_finite"]
     assert d["roofline"]["frac"] > 0 and d["roofline"]["bound"] == "hbm"
+    assert len(d["config"]["ms_per_step_per_rank"]) == 2 and d["config"]["allgather_ms"] is not None
+    # the rows two ranks gather equal the rows of one rank on the same corpus, bit for bit
+    r1 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--recordings", "36", "--steps", "1", "--warmup", "1",
+                         "--no-cpu", "--no-extras", "--dump-rows", str(tmp_path / "rows1.npy")], env=env, capture_output=True, text=True, timeout=600)
+    assert r1.returncode == 0, r1.stdout[-1500:] + r1.stderr[-1500:]
+    assert np.array_equal(np.load(tmp_path / "rows1.npy"), np.load(tmp_path / "rows2.npy"))
+
+
+def test_two_gpus_rccl_rows_equal_one_rank(tmp_path):
+    """The RCCL branch (one process per GPU, device all_gather_into_tensor over xGMI, graphs replayed next to the
+    collective): `bench.py --gpus 2` against `--gpus 1` on the same corpus -- the gathered rows must be equal bit for
+    bit.  Needs two GPUs: skipped on the one-GPU test box, runs wherever the driver has more."""
+    import json, os, subprocess, sys
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs (RCCL over xGMI)")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    out = {}
+    for n in (1, 2):
+        path = str(tmp_path / f"rows{n}.npy")
+        cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", str(n), "--recordings", "64", "--steps", "2", "--warmup", "1",
+               "--no-cpu", "--no-extras", "--dump-rows", path]
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+        d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+        assert d["n_gpus"] == n and d["config"]["result_rows_finite_frac"] == 1.0
+        out[n] = (np.load(path), d)
+    assert out[1][0].shape == out[2][0].shape == (64, 5 * 48)
+    assert np.array_equal(out[1][0], out[2][0])
+    assert out[2][1]["config"]["allgather_ms"] is not None and len(out[2][1]["config"]["ms_per_step_per_rank"]) == 2
