@@ -523,12 +523,12 @@ def front_end_leg(ctx, device, n_sel, n_rec=354, n_samples=4606):
             "matrix_finite": bool(torch.isfinite(out_h).all().item()), "windows_bad_status": bad}
 
 
-def recordings_leg(ctx, device, n_rec=708, shard=236, n_samples=4606):
+def recordings_leg(ctx, device, n_rec=1416, shard=236, n_samples=4606):
     """process_recording whole, from HOST memory (never `value`): raw EEG (47 x 4,606 float64 = 71 windows) and the 250 Hz
     audio envelope of every recording in pinned host buffers -> per shard: upload, five zero-phase band-passes of both,
     the 15 selected windows per recording-band read in place -> corr -> dist -> Rips | tau -> Takens -> Rips ->
     Wasserstein -> rows -> back to the host; the upload of shard k + 1 overlaps the compute of shard k
-    (recordings.RecordingPass).  Half of the corpus' recordings per run, twice."""
+    (recordings.RecordingPass).  The 1,416 recordings of the corpus per run, twice."""
     import torch
     from tda_eeg_audio_amd import recordings
     g = torch.Generator(device="cpu")

@@ -59,12 +59,14 @@ class RecordingPass:
                          y=torch.empty((nb, S * n_ch, L), **f64), ya=torch.empty((nb, S, L), **f64),
                          aw=torch.empty((nb * S * k, self.win), **f64), rows=torch.empty((S, nb, pipeline.RESULT_COLS), **f64),
                          ws=pipeline.Workspace(nb * S * k, seg_off, device, n_ch=n_ch),
+                         work=torch.empty((nb, S * n_ch, L + 2 * edge), **f64), worka=torch.empty((nb, S, L + 2 * 3 * 9), **f64),
+                         # a stream pair per buffer set: the filters of shard k + 1 (chains of dependent operations on few
+                         # waves) run beside the Rips kernels of shard k (which fill the vector units)
+                         main=torch.cuda.Stream(device=device), side=torch.cuda.Stream(device=device),
                          up=torch.cuda.Event(), done=torch.cuda.Event(), down=torch.cuda.Event()) for _ in range(2)]
-        self.work = torch.empty((nb, S * n_ch, L + 2 * edge), **f64)
-        self.worka = torch.empty((nb, S, L + 2 * 3 * 9), **f64)
-        self.copy = torch.cuda.Stream(device=device)
-        self.main = torch.cuda.Stream(device=device)
-        self.side = torch.cuda.Stream(device=device)
+        self.copy = torch.cuda.Stream(device=device)                   # uploads
+        self.back = torch.cuda.Stream(device=device)                   # rows back (its own stream: the download of shard k waits
+                                                                       # for the compute of k, the upload of k + 1 must not)
         self.repairs = 0
 
     def _rips_step(self, st, retry):
@@ -73,18 +75,18 @@ class RecordingPass:
                                  eeg_sliding=(st["y"].view(nb * self.S, self.n_ch, self.L), self.win, self.step, self.sel_t))
 
     def _shard_step(self, st):
-        """Everything between the upload and the rows of one shard, on self.main (the envelopes' filters on self.side)."""
+        """Everything between the upload and the rows of one shard, on its main stream (the envelopes' filters on its side stream)."""
         import torch
         ctx, S, k, nb = self.ctx, self.S, self.k, len(self.bands)
-        self.side.wait_stream(self.main)
-        with torch.cuda.stream(self.side):
-            preprocess.filtfilt_bank_dev(st["env"], self.bas, y_t=st["ya"], work_t=self.worka, ctx=ctx)
+        st["side"].wait_stream(st["main"])
+        with torch.cuda.stream(st["side"]):
+            preprocess.filtfilt_bank_dev(st["env"], self.bas, y_t=st["ya"], work_t=st["worka"], ctx=ctx)
             # create_windows + the selection: a strided view of the band-passed envelopes, gathered into the stack the
             # tau / Takens kernels read (2 KB per window: plumbing)
             st["aw"].view(nb * S, k, self.win).copy_(
                 st["ya"].view(nb * S, self.L).unfold(1, self.win, self.step).index_select(1, self.pick_t))
-        preprocess.bandpass_bank_dev(st["raw"].view(S * self.n_ch, self.L), self.bands, self.fs, y_t=st["y"], work_t=self.work, ctx=ctx)
-        self.main.wait_stream(self.side)
+        preprocess.bandpass_bank_dev(st["raw"].view(S * self.n_ch, self.L), self.bands, self.fs, y_t=st["y"], work_t=st["work"], ctx=ctx)
+        st["main"].wait_stream(st["side"])
         res = self._rips_step(st, "one")                               # (nb * S, 48), band-major groups
         st["rows"].copy_(res.view(nb, S, pipeline.RESULT_COLS).transpose(0, 1))
 
@@ -112,20 +114,20 @@ class RecordingPass:
                     st["raw"][n:].copy_(st["raw"][:1].expand(S - n, -1, -1))
                     st["env"][n:].copy_(st["env"][:1].expand(S - n, -1))
                 st["up"].record(self.copy)
-            with torch.cuda.stream(self.main):
-                self.main.wait_event(st["up"])
+            with torch.cuda.stream(st["main"]):
+                st["main"].wait_event(st["up"])
                 self._shard_step(st)
-                st["done"].record(self.main)
-            with torch.cuda.stream(self.copy):
-                self.copy.wait_event(st["done"])
+                st["done"].record(st["main"])
+            with torch.cuda.stream(self.back):
+                self.back.wait_event(st["done"])
                 rows_h[s0:s0 + n].copy_(st["rows"][:n], non_blocking=True)
-                st["down"].record(self.copy)
+                st["down"].record(self.back)
             pend.append(i)
             if i >= 1:                              # (shard i is queued: the GPU has work while the host looks at shard i - 1)
                 self._verify(pend.pop(0), rows_h, shards)
         while pend:
             self._verify(pend.pop(0), rows_h, shards)
-        self.copy.synchronize()
+        self.back.synchronize()
         return rows_h
 
     def _verify(self, i, rows_h, shards):
@@ -138,8 +140,8 @@ class RecordingPass:
         if bool(st["ws"].flags_host.any()):
             self.repairs += 1
             nb = len(self.bands)
-            with torch.cuda.stream(self.main):
+            with torch.cuda.stream(st["main"]):
                 res = self._rips_step(st, "auto")
                 st["rows"].copy_(res.view(nb, self.S, pipeline.RESULT_COLS).transpose(0, 1))
                 rows_h[s0:s0 + n].copy_(st["rows"][:n])
-                self.main.synchronize()
+                st["main"].synchronize()

@@ -260,3 +260,57 @@ def test_create_dataset_two_ranks_equals_one(ctx, tmp_path):
            "--master-port", str(29700 + os.getpid() % 200), str(script), root, str(tmp_path)]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=dict(os.environ, OMP_NUM_THREADS="1"))
     assert r.returncode == 0 and "DATASET_OK" in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]
+
+
+def test_utils_batch_runs_the_reference_loop_unchanged(ctx):
+    """The per-window loop of process_recording (cmp:88-99), character for character, inside ``with utils.batch():`` --
+    one launch per stage on leaving the block instead of six host round trips per window -- gives the values of the
+    immediate calls (lists of floats / dicts afterwards, NaN and [[0, 0]] semantics included) and is several times faster."""
+    import time
+    from tda_eeg_audio_amd import engine, synth, utils
+    from tda_eeg_audio_amd.utils import (TAKENS_DIM, TAKENS_SUBSAMPLE, compute_audio_persistence, compute_eeg_persistence,
+                                         compute_tau, extract_features, safe_wasserstein, takens_embedding)
+    audio_wins = synth.audio_windows(16, "alpha", seed=77)
+    eeg_dists = engine.corr_dist_batch(synth.eeg_windows(16, seed=78), want_corr=False, ctx=ctx)
+    idx = np.linspace(0, 15, 15, dtype=int)
+    tau = compute_tau(audio_wins[idx[0]], max_lag=125)
+
+    def loop():
+        wass_h0, wass_h1, audio_feat_ts, eeg_feat_ts = [], [], [], []
+        for w in idx:
+            pc = takens_embedding(audio_wins[w], TAKENS_DIM, tau, TAKENS_SUBSAMPLE)
+            if len(pc) < 3:
+                continue
+            a_dgms = compute_audio_persistence(pc)
+            e_dgms = compute_eeg_persistence(eeg_dists[w])
+            wass_h0.append(safe_wasserstein(e_dgms[0], a_dgms[0]))
+            wass_h1.append(safe_wasserstein(e_dgms[1], a_dgms[1]))
+            audio_feat_ts.append(extract_features(a_dgms[1]))
+            eeg_feat_ts.append(extract_features(e_dgms[1]))
+        return wass_h0, wass_h1, audio_feat_ts, eeg_feat_ts
+    loop()                                                # warm
+    t0 = time.perf_counter(); ref = loop(); t_ref = time.perf_counter() - t0
+    with utils.batch():
+        loop()
+    t0 = time.perf_counter()
+    with utils.batch():
+        got = loop()
+    t_got = time.perf_counter() - t0
+    assert len(got[0]) == len(ref[0]) == 15
+    assert float(np.nanmean(got[0])) == float(np.nanmean(ref[0])) and float(np.nanmean(got[1])) == float(np.nanmean(ref[1]))
+    for k in range(15):
+        assert float(got[0][k]) == ref[0][k] and float(got[1][k]) == ref[1][k]
+        for feat in ("mean_persistence", "total_persistence", "persistence_entropy", "max_persistence", "n_features"):
+            assert got[2][k][feat] == ref[2][k][feat] and got[3][k][feat] == ref[3][k][feat]
+        assert dict(got[3][k].items()) == ref[3][k]
+    a_ts = [f["n_features"] for f in got[2]]
+    assert all(isinstance(x, int) for x in a_ts)
+    print(f"per-call loop {t_ref * 1e3:.1f} ms, batched {t_got * 1e3:.1f} ms: x{t_ref / t_got:.1f}")
+    assert t_ref / t_got > 4.0
+    # values are usable inside the block too (the first use flushes what is queued), and errors keep their types
+    with utils.batch():
+        d = compute_eeg_persistence(eeg_dists[0])
+        assert np.asarray(d[0]).shape == (47, 2)
+        assert np.array_equal(np.asarray(d[1]), np.asarray(compute_eeg_persistence(eeg_dists[0])[1]))
+        with pytest.raises(ValueError):
+            compute_eeg_persistence(np.zeros((3, 4)))

@@ -7,6 +7,7 @@ import bench
 from tda_eeg_audio_amd import _lib
 torch.cuda.set_device(0)
 ctx = _lib.get_ctx(0)
+ctx.set_class_words(1, 1)            # the first-pass widths bench.py uses
 n_rec = int(sys.argv[1]) if len(sys.argv) > 1 else 708
 shard = int(sys.argv[2]) if len(sys.argv) > 2 else 236
 r = bench.recordings_leg(ctx, torch.device("cuda", 0), n_rec=n_rec, shard=shard)
