@@ -332,13 +332,15 @@ def main():
                        "first_pass_class_bits": {"eeg": 64 * cw_dm, "audio": 32 * cw_cloud if cw_cloud == 1 else 64},
                        "windows_repaired": {"eeg": int(retry_after[0] - retry_before[0]),
                                             "audio": int(retry_after[1] - retry_before[1]),
+                                            "last_rung": int(retry_after[2] - retry_before[2]),
                                             "note": "windows redone by the widening passes inside the timed steps"},
                        "batches_rerun_with_full_ladder": lanes.repairs,
                        "result_rows_finite_frac": round(finite_frac, 6),
                        "data_generation_s": round(t_gen, 2)},
             "stage_ms": {s: round(v, 4) for s, v in stage_ms.items()},     # one eager pass, every stage alone on the GPU
             "host_loop_ms_per_step": round(t_enq / args.steps * 1e3, 4),
-            "roofline": {"bound": "hbm", "kernel": "rips_cloud_kernel<512, 1, unsigned int> (stage rips_audio)",
+            "roofline": {"bound": "hbm", "kernel": "rips_cloud_kernel<512, 1, unsigned int, false, true> (stage rips_audio: first pass, "
+                                                   "narrow layout, three workgroups per CU)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel_ms": round(kernel_ms, 4),
                          "event_ms": round(float(np.mean(event_ms)), 4), "event_ms_per_batch": [round(x, 4) for x in event_ms],
@@ -351,7 +353,7 @@ def main():
                                  "workgroup end), stamped by the kernel itself (100 MHz wall clock) -- the interval "
                                  "rocprofv3 --kernel-trace reports; `achieved` uses it.  event_ms: HIP events around the "
                                  "same launch on its stream, alone on the GPU (eager warm-up pass)"},
-            "roofline_lds": prof("r02_lds_roofline.json"),
+            "roofline_lds": prof("r03_lds_roofline.json") or prof("r02_lds_roofline.json"),
         }
         vp = (line["roofline_lds"] or {}).get("valu_per_window")
         if vp and args.workload == "corpus":
@@ -363,7 +365,7 @@ def main():
                                      "unit": "G wave-instructions/s", "frac": ach / peak,
                                      "valu_wave_instructions_per_window": vp["total"],
                                      "note": "instructions per window pair from the committed SQ_INSTS_VALU counters "
-                                             "(profiles/r02_sq_counters.json, every kernel of the step), rate from this "
+                                             "(profiles/r03_sq_counters.json, every kernel of the step), rate from this "
                                              "run; peak = CUs x 4 SIMDs x 2.4 GHz / 2 cycles per wave64 instruction (SIMD-32, two or "
                                              "more waves per SIMD)"}
         fp = extras.get("features_pass")

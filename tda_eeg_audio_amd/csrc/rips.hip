@@ -286,7 +286,7 @@ struct Bucketer {
 // the smallest key of the window (kmin_thread: the minimum over the keys this thread produced).  The number of edges
 // within the threshold falls out of the ranking (rank_edges returns it).  red: u32[4] scratch in LDS.
 template <int NT>
-__device__ void effective_threshold(int n, u32 tkey, const u32* vmax, u32 kmin_thread, u32* red, u32& teff_out, u32& kmin_out)
+__device__ __forceinline__ void effective_threshold(int n, u32 tkey, const u32* vmax, u32 kmin_thread, u32* red, u32& teff_out, u32& kmin_out)
 {
     const int tid = threadIdx.x;
     // enclosing radius: every wave takes the minimum over the (<= 128) vertices, two per lane, on the DPP network
@@ -306,7 +306,7 @@ __device__ void effective_threshold(int n, u32 tkey, const u32* vmax, u32 kmin_t
 // key32: E keys (flat index order).  members: E u16 (may share its LDS with ord).  cursor: NB u16 (as NB/2 packed
 // words).  wsum: NT/64 ints.
 template <int NT, int NB, bool WANT_KEYS>
-__device__ int rank_edges(const u32* key32, int E, u32 teff, u32 kmin, u16* members, u32* cursor, int* wsum, u16* rank,
+__device__ __forceinline__ int rank_edges(const u32* key32, int E, u32 teff, u32 kmin, u16* members, u32* cursor, int* wsum, u16* rank,
                           u16* ord, u32* skey)
 {
     static_assert(NB % (2 * NT) == 0, "every thread scans whole words");
@@ -1724,7 +1724,7 @@ __device__ __forceinline__ void rips_sweep(int n, int E, int Ev, const u16* rank
 #define TOT_SLOT_WORDS ((size_t)8128 * TOT_NW)
 
 template <int NT, class KEYFN>
-__device__ void rips_sweep_total(int n, int E, int Ev, const u16* rank, const u16* ord, float* bkey, unsigned char* misc,
+__device__ __forceinline__ void rips_sweep_total(int n, int E, int Ev, const u16* rank, const u16* ord, float* bkey, unsigned char* misc,
                                  u64* __restrict__ psi_g, KEYFN keyfn, double* h0, int h0_cap, double* h1, int h1_cap,
                                  int& out_k0, int& out_k1, int& out_status)
 {
@@ -1872,7 +1872,7 @@ struct KeyFromLds {
 
 // everything after the keys: key32[e] (flat edge order) and vmax[v] = max_u key(v,u) are in LDS, barrier passed
 template <int NT, int NVW, int W, typename WT, bool TOTAL = false>
-__device__ void rips_dm_rest(unsigned char* smem, const int win, int n, float thresh, const u32* vmax, u32 kmin_thread,
+__device__ __forceinline__ void rips_dm_rest(unsigned char* smem, const int win, int n, float thresh, const u32* vmax, u32 kmin_thread,
                              const RipsLayout& L, const RipsOut& out, u64* psi_g = nullptr)
 {
     const int tid = threadIdx.x;
@@ -1915,7 +1915,7 @@ __device__ void rips_dm_rest(unsigned char* smem, const int win, int n, float th
 }
 
 template <int NT, int NVW, int W, typename WT, bool TOTAL = false>
-__device__ void rips_dm_window(unsigned char* smem, const int win, const double* __restrict__ dm, int n, float thresh,
+__device__ __forceinline__ void rips_dm_window(unsigned char* smem, const int win, const double* __restrict__ dm, int n, float thresh,
                                int symmetrise, const RipsLayout& L, const RipsOut& out, u64* psi_g = nullptr)
 {
     const int tid = threadIdx.x;
@@ -1994,7 +1994,7 @@ struct KeyFromPts {
 // hit one address 64 times.  NT / 128 threads per vertex walk the finished row instead, a slice each.  (Not inlined:
 // the point-cloud kernel sits at its register limit and the inlined loop tipped it into spilling.)
 template <int NT>
-__device__ __noinline__ void row_maxima(const u32* key32, u32* vmax, int P)
+__device__ __forceinline__ void row_maxima(const u32* key32, u32* vmax, int P)
 {
     constexpr int TPV = NT / 128;
     const int tid = threadIdx.x;
@@ -2054,7 +2054,7 @@ rips_dm_kernel(const double* __restrict__ dm, int n_win, int n, float thresh, in
 }
 
 template <int NT, int W, typename WT, bool NARROW, bool TOTAL = false>
-__device__ void rips_cloud_window(unsigned char* smem, const int win, const double* __restrict__ src,
+__device__ __forceinline__ void rips_cloud_window(unsigned char* smem, const int win, const double* __restrict__ src,
                                   const int* __restrict__ tau_or_npts, int n_t_or_pcap, int dim, int subsample,
                                   int mode, int normalise, float thresh, const RipsLayout& L, int p_max,
                                   int* __restrict__ n_points, const RipsOut& out, u64* psi_g = nullptr)

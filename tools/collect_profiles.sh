@@ -12,7 +12,7 @@
 # The program sits directly after `--` in every pass.  Summaries go to gpurun_out/<tag>_*; copy what is to be judged
 # into profiles/.
 set -e -o pipefail
-TAG=${1:-r02}
+TAG=${1:-r03}
 OUT=gpurun_out
 mkdir -p $OUT
 export TMPDIR=/tmp
