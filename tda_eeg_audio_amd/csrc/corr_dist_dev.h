@@ -32,11 +32,16 @@ template <int NPRE>
 __device__ __forceinline__ void cd_fetch(double (&pre)[NPRE], const double* __restrict__ X, int ld, int n_ch, int c0,
                                          int tc, int tid)
 {
+    // element k of this thread is (channel (tid >> 6) + 4 k, sample tid & 63): ONE per-thread 32-bit offset and a
+    // uniform row base per k (kept as scalars) -- written the obvious way, X[(size_t)ch * ld + c0 + t], the compiler
+    // keeps twelve 64-bit per-thread offsets alive across the tile loops and spills them
+    const int t = tid & (CD_TCH - 1), ch0 = tid >> CD_TSH;
+    const int toff = ch0 * ld + t;
+    const bool live = t < tc;
 #pragma unroll
     for (int k = 0; k < NPRE; ++k) {
-        const int idx = tid + 256 * k;
-        const int ch = idx >> CD_TSH, t = idx & (CD_TCH - 1);
-        pre[k] = (ch < n_ch && t < tc) ? X[(size_t)ch * ld + c0 + t] : 0.0;
+        const double* rowk = X + (size_t)(4 * k) * (size_t)ld + c0;       // uniform
+        pre[k] = (live && ch0 + 4 * k < n_ch) ? rowk[toff] : 0.0;
     }
 }
 // registers -> time-major LDS tile (row stride CSP = 16 NB + 1 doubles: conflict-free for this write,
