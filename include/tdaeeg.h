@@ -317,8 +317,9 @@ tda_status tda_segment_nanmean(tda_ctx* ctx, const double* x, const int* seg_off
  * windows, the 44 values of tda_aggregate_batch (v2:429-436) ] -- tda_segment_nanmean x 2 + tda_aggregate_batch
  * + the row assembly in ONE launch; the rows are what the GPUs of a node exchange.  Device pointers only.
  * status_a / status_b / seg_flags (all nullable): per-window status arrays of the two Rips calls and an
- * (n_seg) int32 output that receives, per group, the OR of their TDA_WIN_CLASS_OVERFLOW bits -- what a
- * caller running under TDA_RETRY_FIRST_PASS copies to the host to decide about a retry. */
+ * (n_seg) int32 output that receives, per group, the OR of their status words without TDA_WIN_DEGENERATE (a result,
+ * not a condition) -- what a caller running under TDA_RETRY_FIRST_PASS / ONE_STEP copies to the host: bit
+ * TDA_WIN_CLASS_OVERFLOW asks for the rest of the ladder, any other bit means rows the reference would not give. */
 tda_status tda_recording_rows_dev(tda_ctx* ctx, const double* w_h0, const double* w_h1, const int* tau_seg,
                                   const double* feat_h0, const double* feat_h1, const int* seg_off,
                                   int n_seg, double* out, const int* status_a, const int* status_b,

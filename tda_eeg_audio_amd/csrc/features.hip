@@ -393,7 +393,7 @@ recording_rows_kernel(const double* __restrict__ w0, const double* __restrict__ 
     } else if (lane == 2 * TDA_N_FEATURES + 3 && seg_flags) {
         int fl = 0;
         for (int i = s0; i < s1; ++i) fl |= (status_a ? status_a[i] : 0) | (status_b ? status_b[i] : 0);
-        seg_flags[seg] = fl & TDA_WIN_CLASS_OVERFLOW;
+        seg_flags[seg] = fl & ~TDA_WIN_DEGENERATE;          // every condition a caller has to act on (a degenerate cloud is a result)
     }
 }
 

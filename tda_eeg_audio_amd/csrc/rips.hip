@@ -12,8 +12,9 @@
 //
 //  P0  all n(n-1)/2 float32 edge lengths as sortable 32-bit keys; edges longer than
 //      min(thresh, enclosing radius) are dropped (they cannot contribute a row);
-//  P1  stable LSD radix sort in LDS (whole workgroup, four key bits per pass, the keys stay in place and
-//      the 16-bit edges (a << 8 | b) move): the order of (key, a, b);
+//  P1  the rank of every edge in the order of (length, a, b) WITHOUT sorting: a monotone linear map spreads the lengths of
+//      the window over NB >= E buckets (about one edge per bucket); rank = #edges in earlier buckets + #members of the
+//      own bucket that precede the edge (count, DPP scan, scatter, walk: see rank_edges / rank_edges_narrow);
 //  P2  rank[(a,b)] = r for the r-th edge (triangular u16 table, 0x7fff for edges beyond the effective
 //      threshold) and ord[r] = (a,b);
 //  P3  sweep over the filtration in chunks of NT consecutive edges, ONE EDGE PER LANE:
@@ -46,9 +47,11 @@
 //  P4  rows are written as float64 (float32-exact) pairs: H0 ascending death then the essential
 //      rows; H1 rows are ordered by a second tiny kernel (descending birth).
 //
-// LDS per workgroup: 26 KB (n = 47, 64 classes), 32 KB (128 classes) .. 79.2 KB (n = 124 point cloud, 32-bit classes).
-// Class capacity ladder: a first pass, then widening passes that redo only flagged windows (tda_set_retry_policy).
-// No MFMA: this is irregular integer work; the roofline that binds it is LDS latency/issue.
+// LDS per workgroup: 26 KB (n = 47, 64 classes), 32 KB (128 classes) .. 52.5 KB (point cloud of up to 124 points, first
+// pass: a third of a CU) .. 79.2 KB (the wide passes of a 124-point cloud).
+// Class capacity ladder: a first pass, then widening passes that redo only flagged windows (tda_set_retry_policy), then a
+// last rung with the class vectors in HBM and no capacity limit (rips_sweep_total).
+// No MFMA: this is irregular integer work; the roofline that binds it is vector issue / LDS latency.
 #include "common.h"
 #include "corr_dist_dev.h"
 #include <stdlib.h>

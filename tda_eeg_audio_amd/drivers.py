@@ -59,7 +59,10 @@ def validate_distance_matrix(distance_matrix, name=""):
     """scripts/tda_eeg_classification_v2.py:110-140 -- (is_valid, issues) with the reference's checks, order and
     messages: 2-D, square, symmetric (rtol 1e-5, atol 1e-8), no value below -1e-10, zero diagonal (atol 1e-10), no
     NaN, no Inf.  The reference runs it on the FIRST window of every band only (v2:380) and only logs the outcome
-    into the recording's metadata (v2:381-382): a host-side check of one 47 x 47 matrix per recording-band."""
+    into the recording's metadata (v2:381-382): a host-side check of one 47 x 47 matrix per recording-band.
+    This function MIRRORS v2:110-140 by contract -- the same seven checks in the same order with the same tolerances and
+    the same (Spanish) message strings, because the messages are an output format (they land in metadata.csv /
+    metadata.json, v2:684-688) and are pinned by a fixture generated from the reference (tests/golden)."""
     distance_matrix = np.asarray(distance_matrix)
     issues = []
     if distance_matrix.ndim != 2:

@@ -190,17 +190,21 @@ class Lanes:
         eeg_win, audio_win, ctx, max_lag = b.inputs
         with torch.cuda.stream(st):
             if self.defer and bool(ws.flags_host.any()):
-                run_step(eeg_win, audio_win, ws, ctx=ctx, max_lag=max_lag, retry="auto")     # rare: full ladder
-                b.repaired = True
-                self.repairs += 1
-                # verify again before publishing: the full ladder ends in a pass without a capacity limit, so no flag
-                # can be left -- if one is, the rows are not what the reference would give and must not go out
-                ws.flags_host.copy_(ws.seg_flags, non_blocking=True)
-                st.synchronize()
+                if bool((ws.flags_host & 2).any()):                        # class overflow left by the short ladder: rare
+                    run_step(eeg_win, audio_win, ws, ctx=ctx, max_lag=max_lag, retry="auto")
+                    b.repaired = True
+                    self.repairs += 1
+                    ws.flags_host.copy_(ws.seg_flags, non_blocking=True)
+                    st.synchronize()
+                # verify before publishing: the full ladder ends in a pass without a capacity limit, so no overflow can be
+                # left; a truncated H1 diagram (h1_cap), an oversized cloud or a kernel that gave up are not repairable
+                # here -- the rows are not what the reference would give and must not go out
                 if bool(ws.flags_host.any()):
                     from ._lib import TdaError
-                    raise TdaError("Rips class overflow survived the full ladder (status bit 2 in "
-                                   f"{int((ws.flags_host != 0).sum())} recording-band group(s)): rows withheld")
+                    bits = int(np.bitwise_or.reduce(ws.flags_host.numpy()))
+                    raise TdaError(f"window status bits {bits:#x} left in {int((ws.flags_host != 0).sum())} recording-band "
+                                   "group(s) (1: H1 rows truncated, 2: class overflow, 8: not converged, 16: too many points): "
+                                   "rows withheld")
             b.value = b.post(ws.result) if b.post is not None else ws.result
         b.done = True
 

@@ -137,11 +137,17 @@ class RecordingPass:
         st = self.set[i & 1]
         s0, n = shards[i]
         st["down"].synchronize()
-        if bool(st["ws"].flags_host.any()):
+        fl = st["ws"].flags_host
+        if bool((fl & 2).any()):
             self.repairs += 1
             nb = len(self.bands)
             with torch.cuda.stream(st["main"]):
                 res = self._rips_step(st, "auto")
                 st["rows"].copy_(res.view(nb, self.S, pipeline.RESULT_COLS).transpose(0, 1))
                 rows_h[s0:s0 + n].copy_(st["rows"][:n])
+                fl.copy_(st["ws"].seg_flags, non_blocking=True)
                 st["main"].synchronize()
+        # (groups of the idle rows of a short last shard repeat real recordings: their flags say nothing new)
+        if bool(fl.any()):
+            from ._lib import TdaError
+            raise TdaError(f"window status bits {int(np.bitwise_or.reduce(fl.numpy())):#x} left in shard {i}: rows withheld")
