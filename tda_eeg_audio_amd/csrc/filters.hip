@@ -73,26 +73,30 @@ struct SosFilter {
     }
 };
 
-struct BaFilter {
-    double z[F_MAX_TAPS];
+// ND delays (ND = 8 for the reference's 4th-order band-pass and low-pass: ntaps = 9; 16 otherwise)
+template <int ND>
+struct BaFilterN {
+    double z[ND];
     __device__ __forceinline__ void init(const BaParams& p, double x0)
     {
 #pragma unroll
-        for (int k = 0; k < F_MAX_TAPS - 1; ++k) z[k] = p.zi[k] * x0;
+        for (int k = 0; k < ND; ++k) z[k] = p.zi[k] * x0;
     }
     __device__ __forceinline__ double step(const BaParams& p, double xn)
     {
         // scipy/signal/_lfilter.c.in (DOUBLE_filt): yn = Z[0] + b0*xn; Z[n] = Z[n+1] + xn*b[n+1] - yn*a[n+1]
-        // b, a, zi are zero beyond ntaps, so running all F_MAX_TAPS-1 delays is the same recursion:
+        // b, a, zi are zero beyond ntaps, so running all ND >= ntaps - 1 delays is the same recursion:
         // the delay at ntaps-2 reads z[ntaps-1] = 0 and delays above stay 0 (their +0.0 never changes a sum
         // except the sign of an exact zero, which no later operation can observe in y)
         const double yn = z[0] + p.b[0] * xn;
 #pragma unroll
-        for (int n = 0; n < F_MAX_TAPS - 2; ++n) z[n] = (z[n + 1] + xn * p.b[n + 1]) - yn * p.a[n + 1];
-        z[F_MAX_TAPS - 2] = xn * p.b[F_MAX_TAPS - 1] - yn * p.a[F_MAX_TAPS - 1];
+        for (int n = 0; n < ND - 1; ++n) z[n] = (z[n + 1] + xn * p.b[n + 1]) - yn * p.a[n + 1];
+        z[ND - 1] = xn * p.b[ND] - yn * p.a[ND];
         return yn;
     }
 };
+typedef BaFilterN<F_MAX_TAPS - 1> BaFilter;
+typedef BaFilterN<8> BaFilter8;
 
 template <class FILT, class BANK>
 __global__ void __launch_bounds__(FT)
@@ -109,21 +113,31 @@ zero_phase_kernel(const double* __restrict__ x, int n_sig, int L, int edge, BANK
     work += (size_t)blockIdx.y * n_sig * N;
     const bool live = sig < n_sig;
     FILT f;
+    // The kernel is a chain of dependent chunks on very few waves (one lane per signal): the rows of the NEXT chunk are
+    // fetched into registers (64 per lane: rows s0..s0+63, sample c0 + lane of each -- coalesced along the rows) before
+    // the lanes walk the current one, so that the load latency hides behind the recursion.
+    double v[FT];
+    auto fetch_fwd = [&](int c0) {
+        const int cn = (N - c0) < FT ? (N - c0) : FT;
+#pragma unroll
+        for (int r = 0; r < FT; ++r)
+            v[r] = (s0 + r < n_sig && lane < cn) ? odd_ext_at(x + (size_t)(s0 + r) * L, L, edge, c0 + lane) : 0.0;
+    };
+    auto fetch_bwd = [&](int c1) {
+        const int c0 = c1 - FT > 0 ? c1 - FT : 0;
+        const int cn = c1 - c0;
+#pragma unroll
+        for (int r = 0; r < FT; ++r)
+            v[r] = (s0 + r < n_sig && lane < cn) ? work[(size_t)(s0 + r) * N + c0 + lane] : 0.0;
+    };
     // ---- forward over the odd extension, output to work (n_sig, N) ----
+    fetch_fwd(0);
     for (int c0 = 0; c0 < N; c0 += FT) {
         const int cn = (N - c0) < FT ? (N - c0) : FT;
-        // load rows s0..s0+63, samples c0..c0+cn: lane = sample (coalesced along the row)
-        // (sixteen rows per trip, all loads issued before the first one is used: one load latency per trip instead of
-        // one per row -- the kernel is a chain of dependent trips on very few waves)
-        for (int r0 = 0; r0 < FT; r0 += 16) {
-            double v[16];
 #pragma unroll
-            for (int r = 0; r < 16; ++r)
-                v[r] = (s0 + r0 + r < n_sig && lane < cn) ? odd_ext_at(x + (size_t)(s0 + r0 + r) * L, L, edge, c0 + lane) : 0.0;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) tile[(r0 + r) * FTP + lane] = v[r];
-        }
+        for (int r = 0; r < FT; ++r) tile[r * FTP + lane] = v[r];
         __syncthreads();
+        if (c0 + FT < N) fetch_fwd(c0 + FT);
         if (live) {
             if (c0 == 0) f.init(p, tile[lane * FTP]);
             for (int t = 0; t < cn; ++t) tile[lane * FTP + t] = f.step(p, tile[lane * FTP + t]);
@@ -133,19 +147,17 @@ zero_phase_kernel(const double* __restrict__ x, int n_sig, int L, int edge, BANK
             if (s0 + r < n_sig && lane < cn) work[(size_t)(s0 + r) * N + c0 + lane] = tile[r * FTP + lane];
         __syncthreads();
     }
+    __threadfence_block();
+    __syncthreads();                                    // this workgroup's rows of `work` are complete
     // ---- backward over work, trimmed result to y (n_sig, L) ----
+    fetch_bwd(N);
     for (int c1 = N; c1 > 0; c1 -= FT) {
         const int c0 = c1 - FT > 0 ? c1 - FT : 0;
         const int cn = c1 - c0;
-        for (int r0 = 0; r0 < FT; r0 += 16) {
-            double v[16];
 #pragma unroll
-            for (int r = 0; r < 16; ++r)
-                v[r] = (s0 + r0 + r < n_sig && lane < cn) ? work[(size_t)(s0 + r0 + r) * N + c0 + lane] : 0.0;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) tile[(r0 + r) * FTP + lane] = v[r];
-        }
+        for (int r = 0; r < FT; ++r) tile[r * FTP + lane] = v[r];
         __syncthreads();
+        if (c0 > 0) fetch_bwd(c0);
         if (live) {
             if (c1 == N) f.init(p, tile[lane * FTP + cn - 1]);       // zi * y[-1]
             for (int t = cn - 1; t >= 0; --t) tile[lane * FTP + t] = f.step(p, tile[lane * FTP + t]);
@@ -176,7 +188,7 @@ __device__ __forceinline__ double dpp_row_shr1_f64(double v)
 }
 
 template <int LPS>
-__global__ void __launch_bounds__(64)
+__global__ void __launch_bounds__(64, 4)     // (one wave per workgroup, 13 of them per CU for a shard of the corpus: 128 VGPRs)
 sos_pipe_kernel(const double* __restrict__ x, int n_sig, int L, int edge, SosBank bank, double* __restrict__ y,
                 double* __restrict__ work)
 {
@@ -205,21 +217,24 @@ sos_pipe_kernel(const double* __restrict__ x, int n_sig, int L, int edge, SosBan
         if (live) x0 = pass == 0 ? odd_ext_at(x + (size_t)sig * L, L, edge, 0) : work[(size_t)sig * N + N - 1];
         double z0 = zi0 * x0, z1 = zi1 * x0;            // sosfilt_zi * first input sample, every section
         double outp = 0.0;                              // this lane's output of the previous step
-        for (int c0 = 0; c0 < N + LPS - 1; c0 += FT) {
-            // input chunk: positions c0 .. c0+63 of the pass (lane = position: coalesced rows)
-            {   // (all rows' loads in flight before the first is used: one load latency per chunk instead of SPW)
-                const int j = c0 + lane;
-                double v[SPW];
+        // input chunk: positions c0 .. c0+63 of the pass (lane = position: coalesced rows).  The rows of the NEXT chunk are
+        // fetched into registers before the steps of the current one: the load latency hides behind the recursion
+        double v[SPW];
+        auto fetch = [&](int c0) {
+            const int j = c0 + lane;
 #pragma unroll
-                for (int r = 0; r < SPW; ++r) {
-                    v[r] = 0.0;
-                    if (s0 + r < n_sig && j < N)
-                        v[r] = pass == 0 ? odd_ext_at(x + (size_t)(s0 + r) * L, L, edge, j) : work[(size_t)(s0 + r) * N + (N - 1 - j)];
-                }
-#pragma unroll
-                for (int r = 0; r < SPW; ++r) tin[r * FTP + lane] = v[r];
+            for (int r = 0; r < SPW; ++r) {
+                v[r] = 0.0;
+                if (s0 + r < n_sig && j < N)
+                    v[r] = pass == 0 ? odd_ext_at(x + (size_t)(s0 + r) * L, L, edge, j) : work[(size_t)(s0 + r) * N + (N - 1 - j)];
             }
+        };
+        fetch(0);
+        for (int c0 = 0; c0 < N + LPS - 1; c0 += FT) {
+#pragma unroll
+            for (int r = 0; r < SPW; ++r) tin[r * FTP + lane] = v[r];
             __syncthreads();
+            if (c0 + FT < N + LPS - 1) fetch(c0 + FT);
             for (int t = 0; t < FT; ++t) {
                 const int i = c0 + t - s;               // position this lane works on in this step
                 const double from_prev = dpp_row_shr1_f64(outp);
@@ -299,8 +314,12 @@ tda_status launch_filtfilt(tda_ctx* ctx, const double* x, int n_sig, int L, cons
         for (int k = 0; k < F_MAX_TAPS; ++k) { p.b[k] = k < ntaps ? b[f * ntaps + k] / a0 : 0.0; p.a[k] = k < ntaps ? a[f * ntaps + k] / a0 : 0.0; }
         for (int k = 0; k < F_MAX_TAPS; ++k) p.zi[k] = k < ntaps - 1 ? zi[f * (ntaps - 1) + k] : 0.0;
     }
-    hipLaunchKernelGGL((zero_phase_kernel<BaFilter, BaBank>), dim3((n_sig + FT - 1) / FT, n_filt), dim3(FT), 0, st, x, n_sig,
-                       L, edge, bank, y, work);
+    if (ntaps <= 9)
+        hipLaunchKernelGGL((zero_phase_kernel<BaFilter8, BaBank>), dim3((n_sig + FT - 1) / FT, n_filt), dim3(FT), 0, st, x, n_sig,
+                           L, edge, bank, y, work);
+    else
+        hipLaunchKernelGGL((zero_phase_kernel<BaFilter, BaBank>), dim3((n_sig + FT - 1) / FT, n_filt), dim3(FT), 0, st, x, n_sig,
+                           L, edge, bank, y, work);
     TDA_HIP(ctx, hipGetLastError());
     return TDA_OK;
 }
