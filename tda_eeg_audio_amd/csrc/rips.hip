@@ -2000,6 +2000,37 @@ struct KeyFromPts {
     }
 };
 
+// The same with |x|^2 of every point from a table (the key pass: every point takes part in P - 1 edges; the table holds
+// exactly the value the expression above computes, so the keys are bit-identical)
+struct KeyFromPtsTab {
+    const double* pts; const double* nrm; int dim;
+    __device__ __forceinline__ static double norm2(const double* p, int dim)
+    {
+        if (dim == 3) return (p[0] * p[0] + p[1] * p[1]) + p[2] * p[2];
+        double n = 0.0;
+        for (int k = 0; k < dim; ++k) n += p[k] * p[k];
+        return n;
+    }
+    __device__ __forceinline__ float operator()(int, int a, int b) const
+    {
+        double dot = 0.0;
+        if (dim == 3) {
+            const double* pa = pts + 3 * a;
+            const double* pb = pts + 3 * b;
+            dot = fma(pa[2], pb[2], fma(pa[1], pb[1], pa[0] * pb[0]));
+        } else
+        for (int k = 0; k < dim; ++k) {
+            const double xa = pts[a * dim + k], xb = pts[b * dim + k];
+            dot = (k == 0) ? xa * xb : fma(xa, xb, dot);
+        }
+        double d2 = -2.0 * dot;
+        d2 += nrm[a];
+        d2 += nrm[b];
+        if (!(d2 > 0.0)) d2 = 0.0;
+        return (float)sqrt(d2);
+    }
+};
+
 // The row part of max_u d(v,u) for a cloud: the lanes of a wave sit in one or two rows, so an atomic per edge would
 // hit one address 64 times.  NT / 128 threads per vertex walk the finished row instead, a slice each.  (Not inlined:
 // the point-cloud kernel sits at its register limit and the inlined loop tipped it into spilling.)
@@ -2150,11 +2181,15 @@ __device__ __forceinline__ void rips_cloud_window(unsigned char* smem, const int
     u32* cursor = reinterpret_cast<u32*>(smem + (NARROW ? NL::CURSOR : L.off_cursor));
     int* wsum = reinterpret_cast<int*>(rscr + MISC_WV);
     if (tid < 128) vmax[tid] = 0u;
+    // |x|^2 of every point, once (in the bucket cursors' place: they are not in use before the ranking)
+    double* nrm = reinterpret_cast<double*>(cursor);
+    if (tid < P) nrm[tid] = KeyFromPtsTab::norm2(pts + tid * dim, dim);
     __syncthreads();
+    const KeyFromPtsTab kft{pts, nrm, dim};
     u32 kmin_thread = 0xffffffffu;
     for (int e = tid; e < E; e += NT) {
         const int a = edge_row(e), b = e - tri2(a);
-        const u32 sk = f32_sortable(kf(0, a, b));
+        const u32 sk = f32_sortable(kft(0, a, b));
         key32[e] = sk;
         kmin_thread = sk < kmin_thread ? sk : kmin_thread;
         atomicMax(&vmax[b], sk);          // (consecutive lanes: consecutive b, no conflict)
