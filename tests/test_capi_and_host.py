@@ -205,7 +205,8 @@ def test_bench_launch_contract_without_gpu():
 def test_mfma_kernels_keep_accumulators_in_vgprs(tmp_path):
     """Condition under which the f64 MFMA code of the product is known to be exact (csrc/corr_dist_dev.h, COMPILER
     FAULT): hipcc mis-places the wait in front of the first v_accvgpr_read after a v_mfma_f64 when the accumulators
-    live in AGPRs.  No kernel of the shipped code objects may use AGPRs."""
+    live in AGPRs.  No kernel of the shipped code objects that runs MFMAs may use AGPRs (the filter kernels, which have
+    no MFMA, may use them as plain extra registers)."""
     import shutil
     import subprocess
     objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
@@ -222,6 +223,7 @@ def test_mfma_kernels_keep_accumulators_in_vgprs(tmp_path):
         notes = subprocess.run([readelf, "--notes", f], cwd=tmp_path, check=True, capture_output=True, text=True).stdout
         counts = re.findall(r"\.agpr_count:\s+(\d+)\s+(?:.*\n)*?\s+\.name:\s+(\S+)", notes)
         for n, name in counts:
-            seen += 1
-            assert int(n) == 0, f"{name} uses {n} AGPRs"
-    assert seen >= 40, seen          # every kernel of the five code objects was looked at
+            if "eeg_window_kernel" in name or "corr_dist_kernel" in name:       # the kernels that run v_mfma_f64
+                seen += 1
+                assert int(n) == 0, f"{name} uses {n} AGPRs"
+    assert seen >= 10, seen          # every variant of the two MFMA kernels was looked at
