@@ -560,8 +560,8 @@ struct RipsLayout {
     int off_members;                            // ranking phase: keys at 0, then the bucket members
     int off_rank, off_ord, off_aux, off_misc;   // sweep phase: psi at 0, rank, ord; then aux and misc
     int total;
-    // narrow layout (make_narrow_layout): rank at 0, class vectors by rank behind it, `ord` = the chunk table
-    int off_psi, psi_cap, off_cursor, off_rscr;
+    // narrow layout (make_narrow_layout / struct NL): rank at 0, class vectors by rank behind it, `ord` at the end of their region
+    int off_psi, psi_bytes, off_cursor, off_rscr;   // (psi_bytes: the region class vectors and ord share; narrow only)
     int guard[5], n_guard;                      // guard build: where the sentinels end (regions that start there)
 };
 
@@ -2431,7 +2431,7 @@ static RipsLayout make_layout(int n, int psi_bytes_per_edge, int aux_bytes, int 
     const int nb = (NT == 256 && n <= 64) ? 2048 : (NT == 512 ? CLOUD_NB : 8192);
     if (misc_bytes < MISC_SORTCNT + 2 * nb) misc_bytes = MISC_SORTCNT + 2 * nb;
     L.total = align16(L.off_misc + misc_bytes) + GUARD_BYTES;
-    L.off_psi = 0; L.psi_cap = E; L.off_cursor = L.off_misc + MISC_SORTCNT; L.off_rscr = L.off_misc;
+    L.off_psi = 0; L.psi_bytes = 0; L.off_cursor = L.off_misc + MISC_SORTCNT; L.off_rscr = L.off_misc;
     L.guard[0] = L.off_rank; L.guard[1] = L.off_ord; L.guard[2] = L.off_aux; L.guard[3] = L.off_misc; L.guard[4] = L.total;
     L.n_guard = 5;
     return L;
@@ -2442,7 +2442,7 @@ static RipsLayout make_narrow_layout(int n, int dim)      // total == 0: the clo
     static_assert(MISC_BYTES(32) == 8752 + 8 * 32, "NL::MISC assumes this");
     RipsLayout L;
     L.off_rank = NL::RANK; L.off_psi = NL::PSI; L.off_members = NL::MEMBERS; L.off_cursor = NL::CURSOR; L.off_rscr = NL::RSCR;
-    L.off_aux = NL::AUX; L.off_misc = NL::MISC; L.psi_cap = NL::REGION; L.off_ord = 0;
+    L.off_aux = NL::AUX; L.off_misc = NL::MISC; L.psi_bytes = NL::REGION; L.off_ord = 0;
     L.total = (n <= NARROW_PMAX && dim <= NARROW_DIM) ? NL::TOTAL : 0;
     L.guard[0] = NL::PSI; L.guard[1] = NL::MISC; L.guard[2] = NL::AUX; L.guard[3] = NL::TOTAL; L.guard[4] = NL::TOTAL;
     L.n_guard = 4;
