@@ -64,10 +64,10 @@ def parse_args():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the features / PCIe legs")
     ap.add_argument("--no-graph", action="store_true", help="launch every step eagerly instead of replaying HIP graphs")
-    ap.add_argument("--lanes", type=int, default=int(os.environ.get("TDA_LANES", "5")),
-                    help="batches in flight (pipeline.Lanes).  One batch per pass: 2-5 lanes lie within 1 %% on the full "
-                         "corpus, five are 1-2 %% ahead on the share a rank of four or eight holds; one batch per band "
-                         "(--per-band, --workload batch710): one lane per band, +14 %% over three on configs[1]")
+    ap.add_argument("--lanes", type=int, default=int(os.environ.get("TDA_LANES", "3")),
+                    help="batches in flight (pipeline.Lanes), each on ONE stream.  One batch per pass: three lanes are "
+                         "best on the full corpus and on the share a rank of eight holds (2: -1..-4 %%, 5: -0.5..-2 %%; "
+                         "tools/share_ab.sh); one batch per band (--per-band, --workload batch710): one lane per band")
     ap.add_argument("--class-words", default=os.environ.get("TDA_CLASS_WORDS", "1,1"),
                     help="first-pass class capacity (x64 bits for EEG, x32/x64 for audio); windows that need more are "
                          "redone by the widening passes inside the same step and counted in windows_repaired")

@@ -47,7 +47,11 @@ class Workspace:
         self.n_win_seg = torch.from_numpy(np.diff(seg_off).astype(np.float64)).to(device)
         self.side_stream = torch.cuda.Stream(device=device)
         import os
-        self.overlap = os.environ.get("TDA_OVERLAP", "1") != "0"     # EEG chain on a side stream
+        # TDA_OVERLAP=1: EEG chain on a side stream.  Off by default since round 3: a step that forks takes two of the
+        # four hardware queues, so only two lanes make progress at a time and their audio kernels end together,
+        # leaving the CUs to the (latency-bound, nearly empty) widening passes -- measured with tools/share_ab.sh:
+        # one stream per lane is +1.5 % on the full corpus and +9-12 % on the share a rank of eight holds
+        self.overlap = os.environ.get("TDA_OVERLAP", "0") != "0"
         # fused EEG window kernel (corr -> dist -> Rips in one launch, the matrix stays in LDS); "0": the two-kernel
         # path through ws.dist (also taken when the channel count is outside the fused kernel's 33..48)
         self.fused = os.environ.get("TDA_FUSED_EEG", "1") != "0" and 33 <= n_ch <= 48
@@ -93,8 +97,8 @@ def _run_step(eeg_win, audio_win, ws, ctx, max_lag, timers, retry, eeg_sliding=N
         return r
 
     # The EEG chain (corr->dist->Rips) and the audio chain (tau->Takens->Rips) are independent until
-    # the Wasserstein step: the EEG kernels run on a side stream and share the GPU with the audio kernel
-    # (two 78 KB workgroups per CU at most), which leaves CUs idle in the tail of its grid.
+    # the Wasserstein step; with ws.overlap the EEG kernels run on a side stream (see Workspace: not the default,
+    # the other lanes fill the tails better than a fork inside the step does).
     main = torch.cuda.current_stream()
     side = ws.side_stream if ws.overlap else main
     if ws.overlap:
