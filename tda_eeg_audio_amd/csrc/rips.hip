@@ -203,10 +203,12 @@ __device__ __forceinline__ int pair_index(int x, int y) { return x > y ? tri2(x)
 // flat edge index e = tri2(a)+b (a > b)  ->  a
 __device__ __forceinline__ int edge_row(int e)
 {
-    // e < 2^13: 1 + 8e is exact in float and the square root is off by at most one ulp, so the estimate is off by at
-    // most one row -- one branch-free correction instead of two search loops
-    const int a = (int)((1.0f + sqrtf(1.0f + 8.0f * (float)e)) * 0.5f);
-    return a + (tri2(a + 1) <= e ? 1 : 0) - (tri2(a) > e ? 1 : 0);
+    // e < 2^13: 1 + 8e is exact in float and the hardware's v_sqrt_f32 (one ulp, no denormal / class fix-ups: the
+    // correctly rounded sqrtf of -fno-fast-math costs 18 instructions more, tools/probes/valu_rate.hip) puts the estimate
+    // within 1e-4 of (1 + sqrt(1 + 8e)) / 2, i.e. off by at most one row -- one branch-free correction
+    const int a = (int)((1.0f + __builtin_amdgcn_sqrtf(1.0f + 8.0f * (float)e)) * 0.5f);
+    const int t = tri2(a);
+    return a + (t + a <= e ? 1 : 0) - (t > e ? 1 : 0);
 }
 
 // ---------------------------------------------------------------------------------
@@ -435,6 +437,7 @@ struct NL {                                              // byte offsets of the 
     static constexpr int MISC = AUX - NL_GUARD - NL_A16(8752 + 8 * 32);      // MISC_BYTES(32), checked on the host side
     static constexpr int REGION = MISC - NL_GUARD - PSI;  // class vectors from its start, ord at its end
     static_assert(RSCR + 720 <= AUX - NL_GUARD, "the ranking arrays must end in front of the points");
+    static_assert(MEMBERS >= 4 * (E + 1) && CURSOR >= MEMBERS + 2 * (E + 3), "room for the walk's padding (rank_edges_narrow)");
     static_assert(REGION >= 2 * E + 8 * 512, "the first chunks must fit: class vectors of 2 NT ranks next to the whole of ord");
 };
 
@@ -495,6 +498,14 @@ __device__ __forceinline__ int rank_edges_narrow(const u32* key32, int E, u32 te
         const u32 add = (u32)basep * 0x00010001u;     // both halves (sums stay below 65,536)
 #pragma unroll
         for (int i = 0; i < WPT; ++i) cursor[tid * WPT + i] = w[i] + add;
+        // The walk below fetches four members per trip WITHOUT looking at the end of its bucket: members of later
+        // buckets have larger keys and never count, and behind the last bucket lie three entries that name a key of
+        // 0xffffffff (both in the padding that the fixed layout leaves behind the two arrays)
+        if (tid == NT - 1) {
+            const int total = basep + s;
+            members[total] = (u16)NARROW_EMAX; members[total + 1] = (u16)NARROW_EMAX; members[total + 2] = (u16)NARROW_EMAX;
+            const_cast<u32*>(key32)[NARROW_EMAX] = 0xffffffffu;
+        }
     }
     __syncthreads();
     // ---- scatter: afterwards cursor[b] = end of bucket b = start of bucket b + 1 ----
@@ -509,8 +520,8 @@ __device__ __forceinline__ int rank_edges_narrow(const u32* key32, int E, u32 te
     }
     __syncthreads();
     // ---- rank: rank(e) = start of its bucket + the members that precede it in (key, flat index) order.  Four members
-    // per trip; (key, index) pairs are compared as 64-bit numbers; the slots beyond the end of the bucket hold the
-    // edge itself, which does not precede itself ----
+    // per trip; (key, index) pairs are compared as 64-bit numbers; what a trip reads beyond the end of the bucket
+    // belongs to later buckets or is the padding (see the scan) and does not precede the edge ----
     const u16* cur16 = reinterpret_cast<const u16*>(cursor);
     const int Ev = uni((int)cur16[NB - 1]);           // end of the last bucket = edges within the effective threshold
 #pragma unroll
@@ -526,7 +537,7 @@ __device__ __forceinline__ int rank_edges_narrow(const u32* key32, int E, u32 te
             for (int j = lo; j < hi; j += 4) {
                 u32 m[4], km[4];
 #pragma unroll
-                for (int t = 0; t < 4; ++t) m[t] = j + t < hi ? (u32)members[j + t] : e;
+                for (int t = 0; t < 4; ++t) m[t] = (u32)members[j + t];
 #pragma unroll
                 for (int t = 0; t < 4; ++t) km[t] = key32[m[t]];
 #pragma unroll
@@ -2000,6 +2011,25 @@ struct KeyFromPts {
     }
 };
 
+// sqrt of a double >= 0, bit for bit what sqrt() returns: the library's own sequence (v_rsq_f64 and three fused
+// corrections) without its rescaling of tiny arguments and its class test.  Arguments outside {0} u [2^-767, inf) --
+// squares of coordinates below 1e-115, infinities, NaNs -- take the library's path, decided per wave on the high word.
+__device__ __forceinline__ double sqrt_rn(double x)
+{
+    const bool zero = x == 0.0;
+    const u32 hi = (u32)(__double_as_longlong(x) >> 32);
+    if (__builtin_expect(__ballot(hi - 0x10000000u > 0x6fefffffu && !zero) != 0ull, 0)) return sqrt(x);
+    const double y = __builtin_amdgcn_rsq(x);
+    double g = x * y, h = 0.5 * y;
+    const double r = fma(-h, g, 0.5);
+    g = fma(g, r, g); h = fma(h, r, h);
+    double d = fma(-g, g, x);
+    g = fma(d, h, g);
+    d = fma(-g, g, x);
+    g = fma(d, h, g);
+    return zero ? x : g;
+}
+
 // The same with |x|^2 of every point from a table (the key pass: every point takes part in P - 1 edges; the table holds
 // exactly the value the expression above computes, so the keys are bit-identical)
 struct KeyFromPtsTab {
@@ -2027,7 +2057,7 @@ struct KeyFromPtsTab {
         d2 += nrm[a];
         d2 += nrm[b];
         if (!(d2 > 0.0)) d2 = 0.0;
-        return (float)sqrt(d2);
+        return (float)sqrt_rn(d2);
     }
 };
 
