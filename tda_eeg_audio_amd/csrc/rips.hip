@@ -211,6 +211,24 @@ __device__ __forceinline__ int edge_row(int e)
     return a + (t + a <= e ? 1 : 0) - (t > e ? 1 : 0);
 }
 
+// (a << 8 | b) of every flat edge index, as a constant table in device memory: 17 KB that every CU keeps in its vector
+// L1, read with one coalesced load per wave where edge_row() spends 20 vector instructions (the loops over all edges:
+// keys and ord).  Padded by one stride of the widest workgroup so that a loop may fetch one trip ahead unguarded.
+#ifndef TDA_NO_EDGE_TABLE
+struct EdgeTable {
+    u16 v[8192 + 512];
+    constexpr EdgeTable() : v()
+    {
+        int a = 1, b = 0;
+        for (int e = 0; e < 8192 + 512; ++e) { v[e] = (u16)((a << 8) | b); if (++b == a) { ++a; b = 0; } }
+    }
+};
+__device__ const EdgeTable g_edge_ab = EdgeTable();
+__device__ __forceinline__ u32 edge_ab(int e) { return (u32)g_edge_ab.v[e]; }
+#else
+__device__ __forceinline__ u32 edge_ab(int e) { const int a = edge_row(e); return (u32)((a << 8) | (e - tri2(a))); }
+#endif
+
 // ---------------------------------------------------------------------------------
 // Workgroup-wide OR / AND of a predicate with ONE barrier (the library's __syncthreads_or / _and take three
 // and an LDS atomic).  Every wave leaves the verdict of its ballot in its slot, one barrier, everybody reads the
@@ -390,8 +408,7 @@ __device__ __forceinline__ int rank_edges(const u32* key32, int E, u32 teff, u32
     for (int e = tid; e < E; e += NT) {
         const u32 r = rank[e];
         if (r != RANK_NONE) {
-            const int a = edge_row(e);
-            ord[r] = (u16)((a << 8) | (e - tri2(a)));
+            ord[r] = (u16)edge_ab(e);
             if (WANT_KEYS) skey[r] = key32[e];
         }
     }
@@ -554,7 +571,7 @@ __device__ __forceinline__ int rank_edges_narrow(const u32* key32, int E, u32 te
         if (e < E) {
             const u32 r = i & 1 ? rk[i >> 1] >> 16 : rk[i >> 1] & 0xffffu;
             rank[e] = (u16)r;
-            if (r != RANK_NONE) { const int a = edge_row(e); ord[r] = (u16)((a << 8) | (e - tri2(a))); }
+            if (r != RANK_NONE) ord[r] = (u16)edge_ab(e);
         }
     }
     __syncthreads();
@@ -2217,8 +2234,11 @@ __device__ __forceinline__ void rips_cloud_window(unsigned char* smem, const int
     __syncthreads();
     const KeyFromPtsTab kft{pts, nrm, dim};
     u32 kmin_thread = 0xffffffffu;
+    u32 ab_next = edge_ab(tid);                 // (the table is padded: one trip ahead without a guard)
     for (int e = tid; e < E; e += NT) {
-        const int a = edge_row(e), b = e - tri2(a);
+        const u32 ab = ab_next;
+        ab_next = edge_ab(e + NT);
+        const int a = (int)(ab >> 8), b = (int)(ab & 255u);
         const u32 sk = f32_sortable(kft(0, a, b));
         key32[e] = sk;
         kmin_thread = sk < kmin_thread ? sk : kmin_thread;

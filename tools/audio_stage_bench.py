@@ -23,10 +23,11 @@ for _ in range(2):
     engine.takens_rips_dev(W, tau_win, out, ctx=ctx)
 torch.cuda.synchronize()
 ts = []
-for _ in range(6):
+for _ in range(int(os.environ.get('TDA_STAGE_REPS', '6'))):
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     a.record(); engine.takens_rips_dev(W, tau_win, out, ctx=ctx); b.record(); torch.cuda.synchronize()
     ts.append(a.elapsed_time(b))
 bad = int(((out.status & ~4) != 0).sum())
+print("launches (ms):", " ".join(f"{t:.2f}" for t in ts))
 print(f"{os.path.basename(_lib.LIB_PATH)}: {n} audio windows (5 bands): {min(ts):.3f} ms = {n / min(ts) / 1e3:.3f} M windows/s "
       f"[{min(ts) * 106200 / n:.2f} ms per 106,200]; status left non-zero: {bad}; h1 rows {int(out.c1.sum())}")
