@@ -9,7 +9,7 @@ Workload (default `--workload corpus`, BASELINE.json configs[2] + configs[4]): t
 dealt over the N ranks by whole recordings (dist.shard_recordings): STRONG scaling.  A step = ONE pass of the
 per-window hot path over the rank's share, resident in HBM (10 GB of float64 windows at N = 1, so nothing is served
 by the 256 MiB Infinity Cache), all five bands of the share as ONE batch per pass (`--per-band`: one batch per
-band), five passes in flight on their own streams as HIP graphs: per window corr->dist, Rips(EEG 47x47), tau per recording-band, Takens+Rips(audio,
+band), three passes in flight on their own streams as HIP graphs: per window corr->dist, Rips(EEG 47x47), tau per recording-band, Takens+Rips(audio,
 23..123 points over the five bands), Wasserstein H0 and H1, H1/H0 features, the per-recording reductions, and ONE
 all-gather of the (n_rec, 5 x 48) result rows per pass (RCCL over xGMI) inside the timed region -- what replaces
 run_analysis' serial loop (cmp:131-138) and the partial-file merge of scripts/tda_eeg_classification_v2.py:608-638.
@@ -367,7 +367,12 @@ def main():
                                      "note": "instructions per window pair from the committed SQ_INSTS_VALU counters "
                                              "(profiles/r03_sq_counters.json, every kernel of the step), rate from this "
                                              "run; peak = CUs x 4 SIMDs x 2.4 GHz / 2 cycles per wave64 instruction (SIMD-32, two or "
-                                             "more waves per SIMD)"}
+                                             "more waves per SIMD: the guide's figure).  frac_of_measured_issue_rate: against "
+                                             "4 cycles per instruction at the 2.13 GHz the chip holds under load -- what "
+                                             "tools/probes/valu_rate.hip measures for the integer / 64-bit / f64 instructions "
+                                             "these kernels consist of (profiles/r03_valu_rate.txt; only v_add_u32, v_and_b32 "
+                                             "and f32 fma issue in 2)",
+                                     "frac_of_measured_issue_rate": ach / (world * 256 * 4 * 2.13e9 / 4.0)}
         fp = extras.get("features_pass")
         if fp:                                   # secondary: the one HBM-streaming kernel of the step
             nw, ms = fp.pop("eeg_kernel_windows"), fp.pop("eeg_kernel_ms")
