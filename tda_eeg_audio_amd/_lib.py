@@ -11,7 +11,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libtdaeeg.so")
+# TDA_LIB=libtdaeeg_<variant>.so: a diagnostic / A-B build from csrc/Makefile (same directory); the product library otherwise
+LIB_PATH = os.path.join(_HERE, os.path.basename(os.environ.get("TDA_LIB", "libtdaeeg.so")))
 
 c_dp = C.POINTER(C.c_double)
 c_ip = C.POINTER(C.c_int)

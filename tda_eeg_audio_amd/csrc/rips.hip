@@ -1413,9 +1413,11 @@ __device__ __forceinline__ void rips_sweep(int n, int E, int Ev, const u16* rank
                     // a block first catches up with the kills of the blocks before it, then its earliest non-zero
                     // vector kills, is substituted into the rest of ITS block, and so on: one ballot, one count of
                     // trailing zeros and two lane reads per kill on the critical path.
-                    u32 kbit = 0u;
                     WT kvec = 0;
-                    // lane i: mask of the i-th oldest class alive (0 beyond the classes in use)
+                    // lane i: mask of the i-th oldest class alive (0 beyond the classes in use).  A class that is
+                    // killed leaves a zero in its lane: the order of the others stands, and the lanes are closed up
+                    // ONCE after the round (a shift of the order per kill was three DPP moves and four selects on a
+                    // wave that issues one vector instruction every eight cycles, profiles/r03_valu_rate.txt)
                     WT cm = lane < nalive0 ? (WT)1 << ordcls : (WT)0;
                     bool stop = false;
 #pragma unroll
@@ -1424,7 +1426,7 @@ __device__ __forceinline__ void rips_sweep(int n, int E, int Ev, const u16* rank
                         WT v = ev[q].w[0];
                         const u32 myk = ek[q];
                         for (int k = 0; k < nk; ++k) {                 // the kills so far, in their order
-                            const WT m = (WT)1 << rl32(kbit, k);
+                            const WT m = (WT)1 << rl32(mycode, k);
                             const WT w = sizeof(WT) == 8 ? (WT)rl64((u64)kvec, k) : (WT)rl32((u32)kvec, k);
                             if (v & m) v ^= w;
                         }
@@ -1444,25 +1446,28 @@ __device__ __forceinline__ void rips_sweep(int n, int E, int Ev, const u16* rank
                             // ---- off the critical path ----
                             const u32 kk = rl32(myk, src);
                             const float ybirth = __uint_as_float(rl32(__float_as_uint(bky[0]), ybit));
-                            // the class leaves the order: the younger ones move down one lane
-                            const int up = __builtin_amdgcn_update_dpp(0, ordcls, 0x130, 0xF, 0xF, true);     // wave_shl:1 = lane + 1
-                            WT cmup;
-                            if (sizeof(WT) == 8) {
-                                const u32 lo = (u32)__builtin_amdgcn_update_dpp(0, (int)(u32)cm, 0x130, 0xF, 0xF, true);
-                                const u32 hi = (u32)__builtin_amdgcn_update_dpp(0, (int)(u32)((u64)cm >> 32), 0x130, 0xF, 0xF, true);
-                                cmup = (WT)(((u64)hi << 32) | lo);
-                            } else cmup = (WT)(u32)__builtin_amdgcn_update_dpp(0, (int)(u32)cm, 0x130, 0xF, 0xF, true);
-                            if (lane >= opos) { ordcls = up; cm = cmup; }
+                            cm &= (WT)~ybm;                             // the class leaves the order (its lane: zero)
                             // lane j keeps kill j: the image of its class under all LATER kills (lanes beyond hold zero)
-                            if (vimg.w[0] & ybm) vimg.w[0] ^= wvw;
-                            if (lane == nk) {
-                                vimg.w[0] = wvw & (WT)~ybm;
-                                mycode = (u32)ybit; myrk = (u32)(r0 + (int)((kk >> 8) & 0xffffu)); mybirth = ybirth;
-                                kbit = (u32)ybit; kvec = wvw;
-                            }
+                            const bool me = lane == nk;
+                            WT vi = vimg.w[0];
+                            if (vi & ybm) vi ^= wvw;
+                            vimg.w[0] = me ? (WT)(wvw & (WT)~ybm) : vi;
+                            mycode = me ? (u32)ybit : mycode;
+                            myrk = me ? (u32)(r0 + (int)((kk >> 8) & 0xffffu)) : myrk;
+                            mybirth = me ? ybirth : mybirth;
+                            kvec = me ? wvw : kvec;
                             alive[0] &= (WT)~ybm;
                             ++nk;
                         }
+                    }
+                    if (nk > 0) {
+                        // close up the order: the classes still alive move to lanes 0 .. in their order, the other lanes
+                        // go behind them (a permutation: every lane is written)
+                        const bool keep = cm != 0;
+                        const u64 keepb = __ballot(keep);
+                        const int below = (int)__builtin_amdgcn_mbcnt_hi((u32)(keepb >> 32), __builtin_amdgcn_mbcnt_lo((u32)keepb, 0u));
+                        const int dst = keep ? below : __builtin_popcountll(keepb) + (lane - below);
+                        ordcls = __builtin_amdgcn_ds_permute(dst << 2, ordcls);
                     }
                 } else
                 while (true) {
