@@ -299,6 +299,110 @@ tda_status launch_sosfiltfilt(tda_ctx* ctx, const double* x, int n_sig, int L, c
     return TDA_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------
+// The (b, a) recursion with its DELAYS spread over lanes: 8 lanes per signal, lane k keeps z[k].  A step of scipy's
+// direct form II transposed is  yn = z[0] + b0 xn;  z[k] = (z[k+1] + xn b[k+1]) - yn a[k+1]  -- the eight updates are
+// independent of each other once yn is known, so every lane does ONE of them: z[0] is broadcast inside the group of
+// eight (two DPP moves per half), every lane forms the same yn from it, z[k+1] comes from the neighbour lane (row_shl:1).
+// Each delay sees exactly the operations of BaFilterN<8>::step in the same order: bit-identical to scipy.signal.lfilter
+// / filtfilt.  One lane per signal (zero_phase_kernel<BaFilter8>) is a chain of ~30 instructions per sample on 19 waves
+// for the 5 x 236 envelopes of a shard of recordings -- 5 ms with the chip idle, the longest item of the raw-recordings
+// leg; here it is ~15 per sample on 150 waves.
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double dpp_bcast8_f64(double v)
+{
+    // lane & ~7 of every group of eight: quad_perm [0,0,0,0], then the odd quads take the quad before them (row_shr:4)
+    int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x00, 0xF, 0xF, false);
+    int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x00, 0xF, 0xF, false);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, 0x114, 0xF, 0xA, false);
+    hi = __builtin_amdgcn_update_dpp(hi, hi, 0x114, 0xF, 0xA, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double dpp_row_shl1_f64(double v)
+{
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x101, 0xF, 0xF, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x101, 0xF, 0xF, true);
+    return __hiloint2double(hi, lo);
+}
+
+__global__ void __launch_bounds__(64)
+ba_pipe_kernel(const double* __restrict__ x, int n_sig, int L, int edge, BaBank bank, double* __restrict__ y,
+               double* __restrict__ work)
+{
+    constexpr int ND = 8, SPW = 64 / ND;               // delays = lanes per signal; signals per wave
+    __shared__ double tile[SPW * FTP];
+    const BaParams& p = bank.f[blockIdx.y];
+    const int lane = threadIdx.x, g = lane / ND, k = lane % ND;
+    const int s0 = blockIdx.x * SPW;
+    const int N = L + 2 * edge;
+    y += (size_t)blockIdx.y * n_sig * L;
+    work += (size_t)blockIdx.y * n_sig * N;
+    const double b0 = p.b[0], bk = p.b[k + 1], ak = p.a[k + 1], zik = p.zi[k];
+    const bool last = k == ND - 1;
+    double* row = tile + g * FTP;
+    double z = 0.0;
+    auto step = [&](int t) {
+        const double xn = row[t];                       // (one address per group: an LDS broadcast)
+        const double yn = dpp_bcast8_f64(z) + b0 * xn;
+        const double t1 = xn * bk;
+        const double zn = dpp_row_shl1_f64(z);          // z[k + 1]; the last delay has none (scipy: x b[last] - y a[last])
+        const double u = last ? t1 : zn + t1;
+        z = u - yn * ak;
+        if (k == 0) row[t] = yn;
+    };
+    double v[SPW];
+    auto fetch_fwd = [&](int c0) {
+        const int cn = (N - c0) < FT ? (N - c0) : FT;
+#pragma unroll
+        for (int r = 0; r < SPW; ++r)
+            v[r] = (s0 + r < n_sig && lane < cn) ? odd_ext_at(x + (size_t)(s0 + r) * L, L, edge, c0 + lane) : 0.0;
+    };
+    auto fetch_bwd = [&](int c1) {
+        const int c0 = c1 - FT > 0 ? c1 - FT : 0;
+        const int cn = c1 - c0;
+#pragma unroll
+        for (int r = 0; r < SPW; ++r)
+            v[r] = (s0 + r < n_sig && lane < cn) ? work[(size_t)(s0 + r) * N + c0 + lane] : 0.0;
+    };
+    // ---- forward over the odd extension, output to work (n_sig, N) ----
+    fetch_fwd(0);
+    for (int c0 = 0; c0 < N; c0 += FT) {
+        const int cn = (N - c0) < FT ? (N - c0) : FT;
+#pragma unroll
+        for (int r = 0; r < SPW; ++r) tile[r * FTP + lane] = v[r];
+        __syncthreads();
+        if (c0 + FT < N) fetch_fwd(c0 + FT);
+        if (c0 == 0) z = zik * row[0];                  // lfilter_zi * x[0]
+        for (int t = 0; t < cn; ++t) step(t);
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < SPW; ++r)
+            if (s0 + r < n_sig && lane < cn) work[(size_t)(s0 + r) * N + c0 + lane] = tile[r * FTP + lane];
+        __syncthreads();
+    }
+    __threadfence_block();
+    __syncthreads();                                    // this workgroup's rows of `work` are complete
+    // ---- backward over work, trimmed result to y (n_sig, L) ----
+    fetch_bwd(N);
+    for (int c1 = N; c1 > 0; c1 -= FT) {
+        const int c0 = c1 - FT > 0 ? c1 - FT : 0;
+        const int cn = c1 - c0;
+#pragma unroll
+        for (int r = 0; r < SPW; ++r) tile[r * FTP + lane] = v[r];
+        __syncthreads();
+        if (c0 > 0) fetch_bwd(c0);
+        if (c1 == N) z = zik * row[cn - 1];             // zi * y[-1]
+        for (int t = cn - 1; t >= 0; --t) step(t);
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < SPW; ++r) {
+            const int i = c0 + lane;                    // index in the padded signal
+            if (s0 + r < n_sig && lane < cn && i >= edge && i < edge + L) y[(size_t)(s0 + r) * L + i - edge] = tile[r * FTP + lane];
+        }
+        __syncthreads();
+    }
+}
+
 tda_status launch_filtfilt(tda_ctx* ctx, const double* x, int n_sig, int L, const double* b, const double* a,
                            const double* zi, int ntaps, int edge, double* y, double* work, hipStream_t st, int n_filt)
 {
@@ -314,7 +418,12 @@ tda_status launch_filtfilt(tda_ctx* ctx, const double* x, int n_sig, int L, cons
         for (int k = 0; k < F_MAX_TAPS; ++k) { p.b[k] = k < ntaps ? b[f * ntaps + k] / a0 : 0.0; p.a[k] = k < ntaps ? a[f * ntaps + k] / a0 : 0.0; }
         for (int k = 0; k < F_MAX_TAPS; ++k) p.zi[k] = k < ntaps - 1 ? zi[f * (ntaps - 1) + k] : 0.0;
     }
-    if (ntaps <= 9)
+    // ntaps <= 9 (the reference's 4th-order designs): the delays spread over lanes (bit-identical; see ba_pipe_kernel).
+    // TDA_BA_SERIAL=1: the one-lane-per-signal form, kept for measurements
+    static const bool serial = getenv("TDA_BA_SERIAL") != nullptr;
+    if (ntaps <= 9 && !serial)
+        hipLaunchKernelGGL(ba_pipe_kernel, dim3((n_sig + 7) / 8, n_filt), dim3(64), 0, st, x, n_sig, L, edge, bank, y, work);
+    else if (ntaps <= 9)
         hipLaunchKernelGGL((zero_phase_kernel<BaFilter8, BaBank>), dim3((n_sig + FT - 1) / FT, n_filt), dim3(FT), 0, st, x, n_sig,
                            L, edge, bank, y, work);
     else

@@ -33,7 +33,8 @@ def select_windows(n_win, max_windows=MAX_WINDOWS):
 
 class RecordingPass:
     def __init__(self, n_samples, shard, device, ctx=None, n_ch=47, fs=250, bands=preprocess.FREQ_BANDS,
-                 max_windows=MAX_WINDOWS, window_sec=1.0, overlap=0.75):
+                 max_windows=MAX_WINDOWS, window_sec=1.0, overlap=0.75, n_sets=None):
+        import os
         import torch
         from scipy import signal
         self.ctx = ctx or get_ctx()
@@ -55,6 +56,8 @@ class RecordingPass:
         self.sel_t = torch.from_numpy(sel).to(device)
         self.pick_t = torch.from_numpy(self.pick.astype(np.int64)).to(device)
         seg_off = np.arange(0, nb * S * k + 1, k, dtype=np.int32)
+        # buffer sets = shards in flight (upload, filters, step, download of consecutive shards overlap)
+        self.n_sets = int(n_sets or os.environ.get("TDA_REC_SETS", "2"))
         self.set = [dict(raw=torch.empty((S, n_ch, L), **f64), env=torch.empty((S, L), **f64),
                          y=torch.empty((nb, S * n_ch, L), **f64), ya=torch.empty((nb, S, L), **f64),
                          aw=torch.empty((nb * S * k, self.win), **f64), rows=torch.empty((S, nb, pipeline.RESULT_COLS), **f64),
@@ -63,7 +66,7 @@ class RecordingPass:
                          # a stream pair per buffer set: the filters of shard k + 1 (chains of dependent operations on few
                          # waves) run beside the Rips kernels of shard k (which fill the vector units)
                          main=torch.cuda.Stream(device=device), side=torch.cuda.Stream(device=device),
-                         up=torch.cuda.Event(), done=torch.cuda.Event(), down=torch.cuda.Event()) for _ in range(2)]
+                         up=torch.cuda.Event(), done=torch.cuda.Event(), down=torch.cuda.Event()) for _ in range(self.n_sets)]
         self.copy = torch.cuda.Stream(device=device)                   # uploads
         self.back = torch.cuda.Stream(device=device)                   # rows back (its own stream: the download of shard k waits
                                                                        # for the compute of k, the upload of k + 1 must not)
@@ -103,9 +106,9 @@ class RecordingPass:
         shards = [(s0, min(S, n_rec - s0)) for s0 in range(0, n_rec, S)]
         pend = []
         for i, (s0, n) in enumerate(shards):
-            st = self.set[i & 1]
+            st = self.set[i % self.n_sets]
             with torch.cuda.stream(self.copy):
-                if i >= 2:                          # shard i - 2 has read this buffer set and its rows are out
+                if i >= self.n_sets:                # the shard before in this buffer set has read it and its rows are out
                     self.copy.wait_event(st["done"])
                     self.copy.wait_event(st["down"])
                 st["raw"][:n].copy_(raw_h[s0:s0 + n], non_blocking=True)
@@ -123,8 +126,8 @@ class RecordingPass:
                 rows_h[s0:s0 + n].copy_(st["rows"][:n], non_blocking=True)
                 st["down"].record(self.back)
             pend.append(i)
-            if i >= 1:                              # (shard i is queued: the GPU has work while the host looks at shard i - 1)
-                self._verify(pend.pop(0), rows_h, shards)
+            if len(pend) >= self.n_sets:            # (the GPU has the later shards to work on while the host looks at this one;
+                self._verify(pend.pop(0), rows_h, shards)      # its buffer set is the next to be reused)
         while pend:
             self._verify(pend.pop(0), rows_h, shards)
         self.back.synchronize()
@@ -134,7 +137,7 @@ class RecordingPass:
         """Verify, then publish: a shard whose step left a class-overflow flag (run_step copies the flags of its groups
         to pinned memory) is run again with the full ladder -- rare -- and its rows replace the ones already copied."""
         import torch
-        st = self.set[i & 1]
+        st = self.set[i % self.n_sets]
         s0, n = shards[i]
         st["down"].synchronize()
         fl = st["ws"].flags_host
