@@ -193,7 +193,11 @@ sos_pipe_kernel(const double* __restrict__ x, int n_sig, int L, int edge, SosBan
                 double* __restrict__ work)
 {
     constexpr int SPW = 64 / LPS;                      // signals per wave
-    __shared__ double tin[SPW * FTP], tout[SPW * FTP];
+    // ONE tile: the last section's lane writes output position t - (LPS - 1) over input position t in the step in
+    // which the first section's lane has read it (a wave's LDS accesses are served in program order).  Two tiles were
+    // 17 KB per one-wave workgroup: nine per CU where a shard of the corpus brings 13.5 -- a second, half-empty round
+    __shared__ double tin[SPW * FTP];
+    double* tout = tin;
     __shared__ double coef[F_MAX_SEC][8];              // b0 b1 b2 a0 a1 a2 zi0 zi1 per section (identity beyond n_sec)
     const SosParams& p = bank.f[blockIdx.y];
     const int lane = threadIdx.x, sl = lane / LPS, s = lane % LPS;
@@ -235,10 +239,12 @@ sos_pipe_kernel(const double* __restrict__ x, int n_sig, int L, int edge, SosBan
             for (int r = 0; r < SPW; ++r) tin[r * FTP + lane] = v[r];
             __syncthreads();
             if (c0 + FT < N + LPS - 1) fetch(c0 + FT);
+            double x_in = tin[sl * FTP];                // the first section's input, fetched one step ahead (the row is FT + 1 long)
             for (int t = 0; t < FT; ++t) {
                 const int i = c0 + t - s;               // position this lane works on in this step
                 const double from_prev = dpp_row_shr1_f64(outp);
-                const double x_cur = s == 0 ? tin[sl * FTP + t] : from_prev;
+                const double x_cur = s == 0 ? x_in : from_prev;
+                x_in = tin[sl * FTP + t + 1];
                 if (i >= 0 && i < N) {
                     // scipy/signal/_sosfilt.pyx: x_new = b0*x + z0; z0 = (b1*x - a1*x_new + z1); z1 = (b2*x - a2*x_new)
                     const double x_new = b0 * x_cur + z0;
