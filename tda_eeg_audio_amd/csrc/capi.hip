@@ -30,6 +30,7 @@ tda_status tda_ctx_create(int device_id, tda_ctx** out)
     // scratch of the last rung of the Rips ladders, allocated here so that every entry point stays enqueue-only
     e = hipMalloc((void**)&c->total_scratch, rips_total_scratch_bytes());
     if (e != hipSuccess) { g_create_err = std::string("hipMalloc (Rips scratch): ") + hipGetErrorString(e); delete c; return TDA_ERR_HIP; }
+    if (retry_lists_reserve(c, 1 << 19) != TDA_OK) { g_create_err = "hipMalloc (retry lists): " + c->err; tda_ctx_destroy(c); return TDA_ERR_HIP; }
     *out = c;
     return TDA_OK;
 }
@@ -39,6 +40,8 @@ void tda_ctx_destroy(tda_ctx* ctx)
     if (!ctx) return;
     if (ctx->ws) (void)hipFree(ctx->ws);
     if (ctx->total_scratch) (void)hipFree(ctx->total_scratch);
+    for (int i = 0; i < TDA_RETRY_SLOTS; ++i) if (ctx->retry_buf[i]) (void)hipFree(ctx->retry_buf[i]);
+    for (void* q : ctx->retired) (void)hipFree(q);
     delete ctx;
 }
 

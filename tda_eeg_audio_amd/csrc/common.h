@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <string>
+#include <vector>
 #include "../../include/tdaeeg.h"
 
 typedef unsigned long long u64;
@@ -17,6 +18,14 @@ struct tda_ctx {
     unsigned long long* retry_ctr = nullptr;   // tda_set_retry_counter: device u64[4]
     unsigned long long* total_scratch = nullptr;   // class vectors of the last rung of the Rips ladders (rips.hip: TOT_SLOTS x 8.3 MB)
     int h1_order = 0;       // TDA_ORDER_*
+    // Lists of the windows a widening pass has to redo (rips.hip: retry_collect): TDA_RETRY_SLOTS buffers handed out in
+    // turn, one per Rips call, so that calls in flight on different streams (and the HIP graphs that captured them) do
+    // not share one.  [0] = entries, the window indices from [4] on.  Allocated with the context; a call with more
+    // windows than retry_cap replaces them all (the old ones stay alive for graphs that hold their addresses).
+    int* retry_buf[32] = {};
+    int retry_cap = 0;
+    unsigned retry_next = 0;
+    std::vector<void*> retired;
     // host-API staging workspace (grown on demand, only by the host-pointer twins)
     void* ws = nullptr;
     size_t ws_bytes = 0;
@@ -143,6 +152,8 @@ __device__ __forceinline__ float sortable_f32(u32 s)
 
 // launch-side entry points implemented in the .hip files
 size_t rips_total_scratch_bytes();
+#define TDA_RETRY_SLOTS 32
+tda_status retry_lists_reserve(tda_ctx*, int n_win);      // (rips.hip) all slots to at least n_win entries
 tda_status launch_corr_dist(tda_ctx*, const double*, int, int, int, double*, double*, hipStream_t);
 tda_status launch_corr_dist_sliding(tda_ctx*, const double*, int, int, int, int, double*, double*, int*, hipStream_t);
 tda_status launch_corr_to_dist(tda_ctx*, const double*, int, int, int, double*, hipStream_t);

@@ -582,6 +582,7 @@ struct RipsOut {
     double* h0; int h0_cap; int* h0_cnt;
     double* h1; int h1_cap; int* h1_cnt;
     int* status;
+    int* retry_list = nullptr;                  // widening passes: [0] = windows to redo, their indices from [4] on (retry_collect)
 };
 
 struct RipsLayout {
@@ -2100,27 +2101,40 @@ __device__ __forceinline__ void row_maxima(const u32* key32, u32* vmax, int P)
     }
 }
 
-// Widening passes: a workgroup looks at NT status words at a time (one coalesced load, one ballot per wave, the
-// ballots shared through 64 bytes of LDS) and redoes the flagged windows among them.  A pass with nothing to redo
-// costs one load and two barriers per workgroup -- it used to walk the status array one dependent load at a time,
-// 664 of them per workgroup for a band batch of the corpus (2.1 ms per launch, with 95 KB of LDS held meanwhile).
-#define RETRY_SCAN_BEGIN(NT_, status_, n_win_)                                                     \
-    __shared__ u64 retry_flags[NT_ / 64];                                                          \
-    for (int base__ = blockIdx.x * NT_; base__ < (n_win_); base__ += gridDim.x * NT_) {            \
-        const int w__ = base__ + (int)threadIdx.x;                                                 \
-        const u64 bal__ = __ballot(w__ < (n_win_) && ((status_)[w__] & TDA_WIN_CLASS_OVERFLOW));  \
-        if ((threadIdx.x & 63) == 0) retry_flags[threadIdx.x >> 6] = bal__;                        \
-        __syncthreads();                                                                           \
-        for (int wv__ = 0; wv__ < NT_ / 64; ++wv__) {                                              \
-            u64 m__ = retry_flags[wv__];                      /* workgroup-uniform */              \
-            while (m__) {                                                                          \
-                const int win = base__ + 64 * wv__ + __builtin_ctzll(m__);                         \
-                m__ &= m__ - 1ull;
+// Widening passes: the windows the pass before left flagged are collected into a list first (retry_collect_kernel: one
+// coalesced look at every status word, a wave-aggregated append), and workgroup b of the pass redoes entries b,
+// b + gridDim.x, ...: every workgroup gets its share whatever the order of the flags.  (The passes used to walk the
+// status array themselves, NT consecutive words per workgroup: a batch of 17,700 windows kept 35 workgroups busy with ten
+// flagged windows each, one after the other -- 1.2 ms per pass on a nearly empty chip.)  A pass with nothing to redo
+// costs one load per workgroup.
+__global__ void __launch_bounds__(256) retry_collect_kernel(const int* __restrict__ status, int n_win, int* __restrict__ list)
+{
+    const int w = blockIdx.x * 256 + (int)threadIdx.x;
+    const bool f = w < n_win && (status[w] & TDA_WIN_CLASS_OVERFLOW);
+    const u64 bal = __ballot(f);
+    if (bal) {
+        const int lane = (int)threadIdx.x & 63, lead = __builtin_ctzll(bal);
+        int base = 0;
+        if (lane == lead) base = atomicAdd(&list[0], __builtin_popcountll(bal));
+        base = __builtin_amdgcn_readlane(base, lead);
+        if (f) list[4 + base + __builtin_popcountll(bal & ((1ull << lane) - 1ull))] = w;
+    }
+}
+// The pass empties the list when it is through with it ([1] counts the workgroups that are: the last one clears both
+// words), so that the next collection starts from zero without a memset in between.
+#define RETRY_SCAN_BEGIN(NT_, out_, n_win_)                                                        \
+    {                                                                                              \
+        int* rl__ = (out_).retry_list;                                                             \
+        const int nl__ = uni(rl__[0]);                                                             \
+        for (int j__ = blockIdx.x; j__ < nl__; j__ += gridDim.x) {                                 \
+            const int win = uni(rl__[4 + j__]);
 #define RETRY_SCAN_END()                                                                           \
-                __syncthreads();                                                                   \
-            }                                                                                      \
+            __syncthreads();                                                                       \
         }                                                                                          \
-        __syncthreads();                                                                           \
+        if (threadIdx.x == 0 && atomicAdd(&rl__[1], 1) == (int)gridDim.x - 1) {                    \
+            rl__[0] = 0;                                                                           \
+            rl__[1] = 0;                                                                           \
+        }                                                                                          \
     }
 
 // Kernel shell shared by both flavours.  First pass: one workgroup per window.  Retry passes (wider
@@ -2139,7 +2153,7 @@ rips_dm_kernel(const double* __restrict__ dm, int n_win, int n, float thresh, in
         if ((int)blockIdx.x < n_win)
             rips_dm_window<NT, NVW, W, WT>(smem, (int)blockIdx.x, dm, n, thresh, symmetrise, L, out);
     } else {
-        RETRY_SCAN_BEGIN(NT, out.status, n_win)
+        RETRY_SCAN_BEGIN(NT, out, n_win)
             if (retry_ctr && threadIdx.x == 0) atomicAdd(retry_ctr, 1ull);
             rips_dm_window<NT, NVW, W, WT>(smem, win, dm, n, thresh, symmetrise, L, out);
         RETRY_SCAN_END()
@@ -2310,7 +2324,7 @@ rips_cloud_kernel(const double* __restrict__ src, const int* __restrict__ tau_or
             rips_cloud_window<NT, W, WT, NARROW>(smem, (int)blockIdx.x, src, tau_or_npts, n_t_or_pcap, dim, subsample, mode,
                                                  normalise, thresh, L, p_max, n_points, out);
     } else {
-        RETRY_SCAN_BEGIN(NT, out.status, n_win)
+        RETRY_SCAN_BEGIN(NT, out, n_win)
             if (retry_ctr && threadIdx.x == 0) atomicAdd(retry_ctr + 1, 1ull);
             rips_cloud_window<NT, W, WT, false>(smem, win, src, tau_or_npts, n_t_or_pcap, dim, subsample, mode, normalise,
                                                 thresh, L, p_max, n_points, out);
@@ -2336,7 +2350,7 @@ rips_dm_total_kernel(const double* __restrict__ dm, int n_win, int n, float thre
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     u64* psi_g = scratch + (size_t)blockIdx.x * TOT_SLOT_WORDS;
-    RETRY_SCAN_BEGIN(NT, out.status, n_win)
+    RETRY_SCAN_BEGIN(NT, out, n_win)
         if (retry_ctr && threadIdx.x == 0) atomicAdd(retry_ctr + 2, 1ull);
         rips_dm_window<NT, 2, 1, u32, true>(smem, win, dm, n, thresh, symmetrise, L, out, psi_g);
     RETRY_SCAN_END()
@@ -2350,7 +2364,7 @@ rips_cloud_total_kernel(const double* __restrict__ src, const int* __restrict__ 
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     u64* psi_g = scratch + (size_t)blockIdx.x * TOT_SLOT_WORDS;
-    RETRY_SCAN_BEGIN(NT, out.status, n_win)
+    RETRY_SCAN_BEGIN(NT, out, n_win)
         if (retry_ctr && threadIdx.x == 0) atomicAdd(retry_ctr + 2, 1ull);
         rips_cloud_window<NT, 1, u32, false, true>(smem, win, src, tau_or_npts, n_t_or_pcap, dim, subsample, mode, normalise,
                                                    thresh, L, p_max, n_points, out, psi_g);
@@ -2454,7 +2468,7 @@ eeg_window_kernel(WindowSource windows, int n_win, int n_ch, int n_t, float thre
         if ((int)blockIdx.x < n_win)
             eeg_one_window<NB, RES, W, WT>(smem, windows, (int)blockIdx.x, n_ch, n_t, thresh, L, out, dist, corr);
     } else {
-        RETRY_SCAN_BEGIN(256, out.status, n_win)
+        RETRY_SCAN_BEGIN(256, out, n_win)
             if (retry_ctr && threadIdx.x == 0) atomicAdd(retry_ctr, 1ull);
             eeg_one_window<NB, RES, W, WT>(smem, windows, win, n_ch, n_t, thresh, L, out, dist, corr);
         RETRY_SCAN_END()
@@ -2465,6 +2479,37 @@ eeg_window_kernel(WindowSource windows, int n_win, int n_ch, int n_t, float thre
 // host side
 // ---------------------------------------------------------------------------------
 static inline int align16(int x) { return (x + 15) & ~15; }
+
+// ---- lists of the windows to redo (tda_ctx::retry_buf) ----
+tda_status retry_lists_reserve(tda_ctx* ctx, int n_win)
+{
+    if (n_win <= ctx->retry_cap) return TDA_OK;
+    const int cap = (n_win + 1023) & ~1023;
+    for (int i = 0; i < TDA_RETRY_SLOTS; ++i) {
+        int* q = nullptr;
+        TDA_HIP(ctx, hipMalloc((void**)&q, ((size_t)cap + 4) * sizeof(int)));
+        TDA_HIP(ctx, hipMemset(q, 0, 4 * sizeof(int)));                        // (every pass leaves its list empty: see RETRY_SCAN_END)
+        if (ctx->retry_buf[i]) ctx->retired.push_back(ctx->retry_buf[i]);     // (a captured graph may still name it)
+        ctx->retry_buf[i] = q;
+    }
+    ctx->retry_cap = cap;
+    return TDA_OK;
+}
+// one list per Rips call, the slots in turn
+static tda_status retry_list_take(tda_ctx* ctx, int n_win, RipsOut& out)
+{
+    const tda_status rc = retry_lists_reserve(ctx, n_win);
+    if (rc != TDA_OK) return rc;
+    out.retry_list = ctx->retry_buf[ctx->retry_next++ % TDA_RETRY_SLOTS];
+    return TDA_OK;
+}
+// before every widening pass: which windows are flagged now
+static tda_status retry_collect(tda_ctx* ctx, const RipsOut& out, int n_win, hipStream_t st)
+{
+    hipLaunchKernelGGL(retry_collect_kernel, dim3((n_win + 255) / 256), dim3(256), 0, st, out.status, n_win, out.retry_list);
+    TDA_HIP(ctx, hipGetLastError());
+    return TDA_OK;
+}
 
 static RipsLayout make_layout(int n, int psi_bytes_per_edge, int aux_bytes, int NT)   // classes = 8 * psi_bytes_per_edge
 {
@@ -2525,8 +2570,9 @@ static tda_status launch_dm_t(tda_ctx* ctx, const double* dm, int n_win, int n, 
                                          hipFuncAttributeMaxDynamicSharedMemorySize, L.total));
     // retry passes walk the status array on a small strided grid; the widest variant (240 VGPRs, > 80 KB LDS)
     // needs a nearly empty CU per workgroup, so it asks for few of them
-    const int rblocks = (n_win + NT - 1) / NT, rgrid = W >= 8 ? 64 : 256;
-    const int grid = retry_only ? (rblocks < rgrid ? rblocks : rgrid) : n_win;
+    const int rgrid = W >= 8 ? 64 : 512;
+    const int grid = retry_only ? (n_win < rgrid ? n_win : rgrid) : n_win;
+    if (retry_only) { const tda_status rc = retry_collect(ctx, out, n_win, st); if (rc != TDA_OK) return rc; }
     {
         ProbeScope probe(ctx, retry_only ? -1 : TDA_PROBE_RIPS_DM, st);
         hipLaunchKernelGGL(kern, dim3(grid), dim3(NT), L.total, st, dm, n_win, n, thresh, symmetrise, L, out,
@@ -2558,6 +2604,7 @@ static tda_status launch_dm_total(tda_ctx* ctx, const double* dm, int n_win, int
     auto kern = rips_dm_total_kernel<256>;
     if (L.total > 48 * 1024)
         TDA_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, L.total));
+    { const tda_status rc = retry_collect(ctx, out, n_win, st); if (rc != TDA_OK) return rc; }
     hipLaunchKernelGGL(kern, dim3(TOT_SLOTS), dim3(256), L.total, st, dm, n_win, n, thresh, symmetrise, L, out,
                        ctx->total_scratch, ctx->retry_ctr);
     TDA_HIP(ctx, hipGetLastError());
@@ -2576,7 +2623,8 @@ tda_status launch_rips_dm(tda_ctx* ctx, const double* dm, int n_win, int n, doub
     if (h0_cap < n) TDA_FAIL(ctx, TDA_ERR_INVALID, "h0_cap must be >= n");
     RipsOut out{h0, h0_cap, h0_cnt, h1, h1_cap, h1_cnt, status};
     const float th = (float)thresh;
-    tda_status rc;
+    tda_status rc = retry_list_take(ctx, n_win, out);
+    if (rc != TDA_OK) return rc;
     int W = ctx->words_dm < 1 ? 1 : ctx->words_dm;      // (32-bit class words exist in the fused EEG kernel only)
     // largest class capacity that still fits the 160 KiB LDS
     while (W > 1 && make_layout(n, W * 8, n * (n - 1) / 2 * 4, 256).total > LDS_MAX) W >>= 1;
@@ -2626,8 +2674,9 @@ static tda_status launch_eeg_t(tda_ctx* ctx, const WindowSource& win, int n_win,
     if (L.total > 48 * 1024)
         TDA_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, L.total));
-    const int rblocks = (n_win + 255) / 256, rgrid = W >= 8 ? 64 : 256;
-    const int grid = RETRY ? (rblocks < rgrid ? rblocks : rgrid) : n_win;
+    const int rgrid = W >= 8 ? 64 : 512;
+    const int grid = RETRY ? (n_win < rgrid ? n_win : rgrid) : n_win;
+    if (RETRY) { const tda_status rc = retry_collect(ctx, out, n_win, st); if (rc != TDA_OK) return rc; }
     {
         ProbeScope probe(ctx, RETRY ? -1 : TDA_PROBE_RIPS_DM, st);
         hipLaunchKernelGGL(kern, dim3(grid), dim3(256), L.total, st, win, n_win, n_ch, n_t, thresh, L, out, dist, corr,
@@ -2673,6 +2722,7 @@ static tda_status launch_eeg_source(tda_ctx* ctx, const WindowSource& src, int n
     if (n_t < 2 || n_t > CD_RES_CHUNKS * CD_TCH) TDA_FAIL(ctx, TDA_ERR_UNSUPPORTED, "the fused EEG kernel takes windows of 2..256 samples (the reference has 250)");
     if (h0_cap < n_ch) TDA_FAIL(ctx, TDA_ERR_INVALID, "h0_cap must be >= n_ch");
     RipsOut out{h0, h0_cap, h0_cnt, h1, h1_cap, h1_cnt, status};
+    { const tda_status rc0 = retry_list_take(ctx, n_win, out); if (rc0 != TDA_OK) return rc0; }
     // The window is fetched twice (means, then centred products): 128 VGPRs, four workgroups per CU.  The second
     // fetch misses the 4 MB L2 of the XCD (128 windows in flight there) and shows in FETCH_SIZE (181 KB per window
     // against 95 KB algorithmic), but the windows in flight on the whole chip are 96 MB, inside the 256 MiB Infinity
@@ -2723,8 +2773,9 @@ static tda_status launch_cloud_t(tda_ctx* ctx, const double* src, const int* aux
     if (L.total > 48 * 1024)
         TDA_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, L.total));
-    const int rblocks = (n_win + NT - 1) / NT;
-    const int grid = retry_only ? (rblocks < 256 ? rblocks : 256) : n_win;
+    const int rgrid = W >= 2 ? 256 : 512;              // (what fits the chip at once: two / one workgroup per CU)
+    const int grid = retry_only ? (n_win < rgrid ? n_win : rgrid) : n_win;
+    if (retry_only) { const tda_status rc = retry_collect(ctx, out, n_win, st); if (rc != TDA_OK) return rc; }
     {
         ProbeScope probe(ctx, retry_only ? -1 : TDA_PROBE_RIPS_CLOUD, st);
         hipLaunchKernelGGL(kern, dim3(grid), dim3(NT), L.total, st, src, aux, n_win, n_t_or_pcap, dim, subsample, mode,
@@ -2759,7 +2810,8 @@ tda_status launch_rips_cloud(tda_ctx* ctx, const double* src, const int* aux, in
     if (h0_cap < p_max) TDA_FAIL(ctx, TDA_ERR_INVALID, "h0_cap must be >= max points per cloud");
     RipsOut out{h0, h0_cap, h0_cnt, h1, h1_cap, h1_cnt, status};
     const float th = (float)thresh;
-    tda_status rc = TDA_OK;
+    tda_status rc = retry_list_take(ctx, n_win, out);
+    if (rc != TDA_OK) return rc;
     // class capacity ladder: 32 bits (two workgroups per CU for 124-point clouds), then 64, then 128
     // while the table fits LDS; each wider pass only redoes the windows the previous one flagged
     const bool fits128 = make_layout(p_max, 16, p_max * dim * 8, CLOUD_NT).total <= LDS_MAX;
@@ -2792,6 +2844,8 @@ tda_status launch_rips_cloud(tda_ctx* ctx, const double* src, const int* aux, in
         auto kern = rips_cloud_total_kernel<CLOUD_NT>;
         if (L.total > 48 * 1024)
             TDA_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, L.total));
+        rc = retry_collect(ctx, out, n_win, st);
+        if (rc != TDA_OK) return rc;
         hipLaunchKernelGGL(kern, dim3(TOT_SLOTS), dim3(CLOUD_NT), L.total, st, src, aux, n_win, n_t_or_pcap, dim, subsample, mode,
                            normalise, th, L, p_max, n_points, out, ctx->total_scratch, ctx->retry_ctr);
         TDA_HIP(ctx, hipGetLastError());
