@@ -2138,8 +2138,8 @@ __global__ void __launch_bounds__(256) retry_collect_kernel(const int* __restric
     }
 
 // Kernel shell shared by both flavours.  First pass: one workgroup per window.  Retry passes (wider
-// class vector) run a small grid that strides over the windows and only redoes the ones the previous
-// pass flagged, so a retry with nothing to do costs a few microseconds instead of n_win LDS-heavy
+// class vector) run a grid that fits the chip and redo the windows on the list of the flagged ones
+// (RETRY_SCAN_BEGIN), so a retry with nothing to do costs a few microseconds instead of n_win LDS-heavy
 // workgroup launches.
 // 64 and 128 classes: four waves per SIMD (128 VGPRs, no spills).  Five (96 VGPRs, 32 B of scratch per lane) paid while
 // the sweep spent its time at barriers; with the one-barrier votes four is 1 % faster end to end
@@ -2568,7 +2568,7 @@ static tda_status launch_dm_t(tda_ctx* ctx, const double* dm, int n_win, int n, 
     if (L.total > 48 * 1024)
         TDA_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, L.total));
-    // retry passes walk the status array on a small strided grid; the widest variant (240 VGPRs, > 80 KB LDS)
+    // retry passes work off the list of flagged windows on a grid that fits the chip; the widest variant (240 VGPRs, > 80 KB LDS)
     // needs a nearly empty CU per workgroup, so it asks for few of them
     const int rgrid = W >= 8 ? 64 : 512;
     const int grid = retry_only ? (n_win < rgrid ? n_win : rgrid) : n_win;
