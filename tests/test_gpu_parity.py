@@ -354,6 +354,44 @@ def test_last_rung_alone_on_ordinary_windows(ctx):
         ctx.set_retry_policy(ctx.RETRY_AUTO)
 
 
+def test_widening_passes_redo_exactly_the_flagged_windows(ctx):
+    """The widening passes work off a list of the flagged windows (rips.hip: retry_collect_kernel).  Hand-made flags on a
+    batch larger than any retry grid -- every window, every third one, none -- redone by the widening kernels alone
+    (TDA_RETRY_ONLY): the flagged windows get the diagrams of an ordinary run bit for bit, the others are not touched
+    (their rows stay the poison written beforehand), and a second pass over the emptied list changes nothing."""
+    import torch
+    dev = torch.device("cuda", 0)
+    n = 1500
+    wins, _ = synth.audio_windows_all_bands(n // 5, seed=11)
+    wins = wins[:n]
+    wt = torch.from_numpy(np.ascontiguousarray(wins)).to(dev)
+    tau = engine.tau_dev(wt, max_lag=125, ctx=ctx)
+    ref = engine.takens_rips_dev(wt, tau, ctx=ctx)
+    torch.cuda.synchronize()
+    assert not ref.status.cpu().numpy().any()
+    r0, r1 = ref.to_lists()
+    for every in (1, 3, 0):
+        out = engine.DeviceDiagrams(n, 128, engine.DEFAULT_H1_CAP, dev)
+        out.status.zero_(); out.c0.fill_(-5); out.c1.fill_(-5)
+        flagged = np.zeros(n, bool)
+        if every:
+            flagged[::every] = True
+            out.status[torch.from_numpy(np.nonzero(flagged)[0]).to(dev)] = 2
+        ctx.set_retry_policy(ctx.RETRY_ONLY)
+        try:
+            for _ in range(2):
+                engine.takens_rips_dev(wt, tau, out, ctx=ctx)
+        finally:
+            ctx.set_retry_policy(ctx.RETRY_AUTO)
+        torch.cuda.synchronize()
+        c0, c1, st = out.c0.cpu().numpy(), out.c1.cpu().numpy(), out.status.cpu().numpy()
+        assert not st.any()
+        assert (c0[~flagged] == -5).all() and (c1[~flagged] == -5).all()
+        h0 = out.h0.cpu().numpy(); h1 = out.h1.cpu().numpy()
+        for w in np.nonzero(flagged)[0][:: max(1, int(flagged.sum()) // 200)]:
+            assert _same_multiset(h0[w, :c0[w]], r0[w]) and _same_multiset(h1[w, :c1[w]], r1[w]), (every, int(w))
+
+
 def test_rips_h1_truncation_flag(ctx):
     W = synth.eeg_windows(4, seed=3, kind="white")
     dist = engine.corr_dist_batch(W, want_corr=False, ctx=ctx)
