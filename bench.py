@@ -456,7 +456,9 @@ def features_leg(args, ctx, device, mine, shards, n_rec, rank, world, nb):
 
 def pcie_leg(ctx, device, eeg_b, aud_b, wpr, n_rec=256):
     """PCIe-inclusive rate (never `value`): pinned host windows -> HBM -> the same step -> result rows back to the
-    host, copies and kernels on one stream; a bounded sample of one band's batch."""
+    host, copies and kernels on one stream; a bounded sample of one band's batch.  (One stream on purpose: with the
+    upload of the next batch on its own stream beside the step the copy drops from 57 to 42 GB/s and the leg from 0.47 to
+    0.44 M windows/s -- measured in round 3; the leg is bound by the link either way: 94 KB per window.)"""
     import torch
     from tda_eeg_audio_amd import pipeline
     n_win = min(eeg_b.shape[0], n_rec * wpr)
