@@ -4,8 +4,14 @@
 #pragma once
 #include "common.h"
 
-#define CD_TCH 64         // time samples per LDS tile
-#define CD_TSH 6          // log2(CD_TCH)
+// 32 samples per tile since round 3 (64 before): the tile is the largest item of the fused EEG kernel's LDS (25 KB of
+// 38) and twelve prefetch registers per lane; at 32 the kernel needs 26.9 KB and 80 VGPRs -- six workgroups per CU
+// instead of four, fused kernel 4.15 -> 3.61 ms per 55,224 windows.  The sums run over the samples in the same order
+// whatever the tile length (the accumulators wait in LDS between tiles): bit-identical results.
+#ifndef CD_TCH
+#define CD_TCH 32         // time samples per LDS tile
+#define CD_TSH 5          // log2(CD_TCH)
+#endif
 #define CD_MAXCH 64
 
 typedef double d4 __attribute__((ext_vector_type(4)));
@@ -27,21 +33,24 @@ typedef double d4 __attribute__((ext_vector_type(4)));
 
 
 // global -> registers (issued early, consumed after the current tile has been used).  Element
-// idx = tid + 256 k of a tile is (channel idx / 64, sample idx % 64): a wave reads 512 contiguous bytes.
+// idx = tid + 256 k of a tile is (channel idx / CD_TCH, sample idx % CD_TCH): a wave reads 64 / CD_TCH rows of
+// 8 CD_TCH contiguous bytes.
 template <int NPRE>
 __device__ __forceinline__ void cd_fetch(double (&pre)[NPRE], const double* __restrict__ X, int ld, int n_ch, int c0,
                                          int tc, int tid)
 {
-    // element k of this thread is (channel (tid >> 6) + 4 k, sample tid & 63): ONE per-thread 32-bit offset and a
-    // uniform row base per k (kept as scalars) -- written the obvious way, X[(size_t)ch * ld + c0 + t], the compiler
-    // keeps twelve 64-bit per-thread offsets alive across the tile loops and spills them
+    // element k of this thread is (channel (tid >> CD_TSH) + CPK k, sample tid & (CD_TCH - 1)), CPK = 256 / CD_TCH
+    // channels per round of the workgroup: ONE per-thread 32-bit offset and a uniform row base per k (kept as scalars)
+    // -- written the obvious way, X[(size_t)ch * ld + c0 + t], the compiler keeps twelve 64-bit per-thread offsets
+    // alive across the tile loops and spills them
+    constexpr int CPK = 256 / CD_TCH;
     const int t = tid & (CD_TCH - 1), ch0 = tid >> CD_TSH;
     const int toff = ch0 * ld + t;
     const bool live = t < tc;
 #pragma unroll
     for (int k = 0; k < NPRE; ++k) {
-        const double* rowk = X + (size_t)(4 * k) * (size_t)ld + c0;       // uniform
-        pre[k] = (live && ch0 + 4 * k < n_ch) ? rowk[toff] : 0.0;
+        const double* rowk = X + (size_t)(CPK * k) * (size_t)ld + c0;     // uniform
+        pre[k] = (live && ch0 + CPK * k < n_ch) ? rowk[toff] : 0.0;
     }
 }
 // registers -> time-major LDS tile (row stride CSP = 16 NB + 1 doubles: conflict-free for this write,
@@ -62,7 +71,7 @@ __device__ __forceinline__ void cd_stash(const double (&pre)[NPRE], double* tile
     }
 }
 
-#define CD_RES_CHUNKS 4   // windows of up to CD_RES_CHUNKS * CD_TCH samples stay in registers between the passes
+#define CD_RES_CHUNKS (256 / CD_TCH)   // windows of up to CD_RES_CHUNKS * CD_TCH samples stay in registers between the passes
 
 
 template <int NB>

@@ -2459,7 +2459,12 @@ __device__ __forceinline__ void eeg_one_window(unsigned char* smem, const Window
 #define TDA_EEG_WIDE_WAVES 2     // (tools/probes/wide_waves_repro.py builds with 1 to reproduce the fault)
 #endif
 template <int NB, bool RES, int W, bool RETRY, typename WT>
-__global__ void __launch_bounds__(256, (W > 2 || RETRY) ? TDA_EEG_WIDE_WAVES : (RES ? 3 : 4))
+// first pass of the fused kernel: six workgroups per CU (80 VGPRs, 24 B of scratch per lane; 26.9 KB of LDS with
+// 32-sample tiles).  Four (111 VGPRs, 38 KB with 64-sample tiles) left half the issue slots empty: +13 % on the kernel
+#ifndef TDA_EEG_WAVES
+#define TDA_EEG_WAVES 6
+#endif
+__global__ void __launch_bounds__(256, (W > 2 || RETRY) ? TDA_EEG_WIDE_WAVES : (RES ? 3 : TDA_EEG_WAVES))
 eeg_window_kernel(WindowSource windows, int n_win, int n_ch, int n_t, float thresh, RipsLayout L, RipsOut out,
                   double* __restrict__ dist, double* __restrict__ corr, unsigned long long* __restrict__ retry_ctr)
 {
