@@ -81,6 +81,25 @@ __device__ __forceinline__ u64 uni64(u64 v)
     u32 hi = (u32)__builtin_amdgcn_readfirstlane((int)(u32)(v >> 32));
     return ((u64)hi << 32) | lo;
 }
+// sqrt of a double >= 0, bit for bit what sqrt() returns: the library's own sequence (v_rsq_f64 and three fused
+// corrections) without its rescaling of tiny arguments and its class test.  Arguments outside {0} u [2^-767, inf) --
+// squares of coordinates below 1e-115, infinities, NaNs -- take the library's path, decided per wave on the high word.
+__device__ __forceinline__ double sqrt_rn(double x)
+{
+    const bool zero = x == 0.0;
+    const u32 hi = (u32)(__double_as_longlong(x) >> 32);
+    if (__builtin_expect(__ballot(hi - 0x10000000u > 0x6fefffffu && !zero) != 0ull, 0)) return sqrt(x);
+    const double y = __builtin_amdgcn_rsq(x);
+    double g = x * y, h = 0.5 * y;
+    const double r = fma(-h, g, 0.5);
+    g = fma(g, r, g); h = fma(h, r, h);
+    double d = fma(-g, g, x);
+    g = fma(d, h, g);
+    d = fma(-g, g, x);
+    g = fma(d, h, g);
+    return zero ? x : g;
+}
+
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
 
 // ---- wave64 reductions on the DPP network (a few VALU cycles per step; __shfl_xor goes through

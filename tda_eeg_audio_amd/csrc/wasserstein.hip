@@ -65,7 +65,7 @@ __device__ __forceinline__ double ws_cost(double ab, double ad, double bb, doubl
     d2 += xx;
     d2 += yy;
     if (!(d2 > 0.0)) d2 = 0.0;
-    return sqrt(d2);
+    return sqrt_rn(d2);                         // (sqrt() bit for bit, six instructions less: common.h)
 }
 
 template <int CW>
@@ -197,7 +197,7 @@ wasserstein_kernel(const double* __restrict__ dgm_a, const int* __restrict__ cnt
                 d2 += a_is_row ? r_n : c_n;                             // |x|^2 of the FIRST diagram's point, then the second's
                 d2 += a_is_row ? c_n : r_n;
                 if (!(d2 > 0.0)) d2 = 0.0;
-                const double g = sqrt(d2) - r_s - ct[j];
+                const double g = sqrt_rn(d2) - r_s - ct[j];
                 return g < 0.0 ? g : 0.0;
             };
             for (int t = 0; t < nsteps1d; ++t) {
