@@ -34,6 +34,7 @@ extern "C" __attribute__((visibility("default"))) int tda_profile_read_ws(unsign
 #define WCLK() 0ull
 #endif
 
+#define WS_DEFERRED 0x40000000      // status of a pair between the small and the wide launch (never seen by the caller)
 #define WS_CP 0.7071067811865476   // np.cos(np.pi/4)
 #define WS_SP 0.7071067811865475   // np.sin(np.pi/4)
 
@@ -74,11 +75,15 @@ wasserstein_kernel(const double* __restrict__ dgm_a, const int* __restrict__ cnt
                    const double* __restrict__ dgm_b, const int* __restrict__ cnt_b, int cap_b,
                    const int* __restrict__ idx_a, const int* __restrict__ idx_b, int n_pairs,
                    int max_rows, int max_cols,
-                   double* __restrict__ out, int* __restrict__ status)
+                   double* __restrict__ out, int* __restrict__ status, int mode)
 {
+    // mode 1: the SMALL first launch (LDS for 64 x 64 points whatever the capacities of the diagram buffers: four times
+    // the workgroups per CU of a launch sized by a capacity of 256) leaves pairs that do not fit marked WS_DEFERRED;
+    // mode 2: the launch sized by the capacities takes exactly those; mode 0: one launch for everything
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int pr = blockIdx.x;
     if (pr >= n_pairs) return;
+    if (mode == 2 && status[pr] != WS_DEFERRED) return;
     const int lane = lane_id();
     unsigned long long wt0 = WCLK();
     (void)wt0;
@@ -115,7 +120,10 @@ wasserstein_kernel(const double* __restrict__ dgm_a, const int* __restrict__ cnt
     const int R = a_is_row ? Me : Ne, Cn = a_is_row ? Ne : Me;
     const int cw_used = (Cn + 63) >> 6;                // column slots per lane actually in use
     if (R > max_rows || Cn > max_cols || Cn > 64 * CW) {
-        if (lane == 0) { out[pr] = __longlong_as_double(0x7ff8000000000000ll); status[pr] = TDA_WIN_NOT_CONVERGED; }
+        if (lane == 0) {
+            if (mode == 1) status[pr] = WS_DEFERRED;
+            else { out[pr] = __longlong_as_double(0x7ff8000000000000ll); status[pr] = TDA_WIN_NOT_CONVERGED; }
+        }
         return;
     }
     // load finite points, preserving order
@@ -420,6 +428,16 @@ tda_status launch_wasserstein(tda_ctx* ctx, const double* dgm_a, const int* cnt_
     // pair) left room for 5-7 one-wave workgroups per CU; without it the H0 pairs of a pass take 1.7 instead of 2.9 ms
     // and the H1 pairs 0.73 instead of 1.17 ms (latency-bound solver: residency matters more than the re-evaluation).
     const size_t lds = (size_t)(4 * max_rows + 4 * max_cols + ((max_cols + 1) >> 1)) * 8;
+    // diagram buffers with room for more than 128 rows (H1: 256) are mostly far from full (35 x 41 rows on the bench's
+    // windows): a first launch with LDS for 64 x 64 points, the launch sized by the capacities for the pairs it defers
+    static const bool small_first = getenv("TDA_WS_ONE_LAUNCH") == nullptr;
+    const int mode = (small_first && max_cols > 128) ? 2 : 0;
+    if (mode) {
+        const int sr = max_rows < 64 ? max_rows : 64;
+        const size_t lds_s = (size_t)(4 * sr + 4 * 64 + 32) * 8;
+        hipLaunchKernelGGL(wasserstein_kernel<1>, dim3(n_pairs), dim3(64), lds_s, st, dgm_a, cnt_a, cap_a, dgm_b, cnt_b, cap_b,
+                           idx_a, idx_b, n_pairs, sr, 64, out, status, 1);
+    }
 #define WS_LAUNCH(CWV)                                                                                         \
     do {                                                                                                       \
         auto kern = wasserstein_kernel<CWV>;                                                                   \
@@ -427,7 +445,7 @@ tda_status launch_wasserstein(tda_ctx* ctx, const double* dgm_a, const int* cnt_
             TDA_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                              \
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));           \
         hipLaunchKernelGGL(kern, dim3(n_pairs), dim3(64), lds, st, dgm_a, cnt_a, cap_a, dgm_b, cnt_b, cap_b,   \
-                           idx_a, idx_b, n_pairs, max_rows, max_cols, out, status);                \
+                           idx_a, idx_b, n_pairs, max_rows, max_cols, out, status, mode);                      \
     } while (0)
     if (max_cols <= 128) WS_LAUNCH(2);
     else if (max_cols <= 256) WS_LAUNCH(4);

@@ -571,6 +571,16 @@ def test_wasserstein_vs_persim_restatement_and_bruteforce(ctx):
     # symmetry
     out2 = engine.wasserstein_batch(rb, cb, ra, ca, ctx=ctx)
     assert np.abs(out - out2).max() < 1e-10
+    # buffers of 256 rows (the H1 capacity of the pipeline): the small first launch takes the pairs of up to 64 x 64
+    # points, the launch sized by the capacities the rest -- sizes on both sides of the limit, in one batch
+    sizes = [(0, 0), (1, 64), (64, 64), (65, 3), (64, 65), (100, 100), (3, 250), (200, 130), (40, 41), (63, 64)]
+    As = [np.sort(rng.random((m, 2)), axis=1) for m, _ in sizes]
+    Bs = [np.sort(rng.random((n, 2)), axis=1) for _, n in sizes]
+    ra, ca = engine.pack_diagrams(As, cap=256); rb, cb = engine.pack_diagrams(Bs, cap=256)
+    out, st = engine.wasserstein_batch(ra, ca, rb, cb, ctx=ctx, want_status=True)
+    assert not st.any()
+    ref = np.array([brute.safe_wasserstein_oracle(a, b) for a, b in zip(As, Bs)])
+    assert np.abs(out - ref).max() < 1e-10, np.abs(out - ref)
     # exhaustive optimum for tiny diagrams
     As = [np.sort(rng.random((int(rng.integers(1, 5)), 2)), axis=1) for _ in range(20)]
     Bs = [np.sort(rng.random((int(rng.integers(1, 5)), 2)), axis=1) for _ in range(20)]
