@@ -9,6 +9,7 @@
 // n <= 128, halving above) so that mean/std agree with np.mean/np.std to the last bit on the
 // same input order; log() is OCML's, so the entropy is compared with a 1e-12 tolerance.
 #include "common.h"
+#include <climits>
 
 // numpy's pairwise sum over f(lo) .. f(lo+n-1), evaluated redundantly by every lane that
 // calls it (n is tiny: <= a few hundred).  The leaf (n <= 128: every diagram and group of the path) is inlined into
@@ -185,8 +186,11 @@ __device__ __forceinline__ void wave_sync()
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
 }
-__global__ void __launch_bounds__(64 * FIN_WAVES, 5)
-diagram_finish_kernel(DiagramSets S, int n_dgm, int lds_cap)
+// A launch takes the diagrams with k_lo < rows <= lds_cap: the first one has slices of 64 rows (8 KB per workgroup:
+// eight workgroups = every wave slot of a CU), a second one, sized by the capacities of the buffers (H1: 256 rows,
+// 32 KB per workgroup, five per CU), the larger diagrams -- its other waves leave after one load.
+__global__ void __launch_bounds__(64 * FIN_WAVES, 8)
+diagram_finish_kernel(DiagramSets S, int n_dgm, int lds_cap, int k_lo)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int wv = uni((int)(threadIdx.x >> 6));
@@ -201,6 +205,7 @@ diagram_finish_kernel(DiagramSets S, int n_dgm, int lds_cap)
     const int lane = lane_id();
     int k = S.cnt[set][g];
     k = k < cap ? k : cap;
+    if (k > lds_cap || k <= k_lo) return;              // (wave-uniform: another launch's diagram)
     double* rows = S.rows[set] + (size_t)g * cap * 2;
     double* feat = S.feat[set];
     const bool reorder = S.order[set] && k >= 2;
@@ -514,14 +519,23 @@ tda_status launch_diagram_finish(tda_ctx* ctx, const tda_diagram_set* sets, int 
         }
     }
     S.n_sets = n_sets;
+    const long long n_all = (long long)n_sets * n_dgm;
+    // small diagrams first (see the kernel), then whatever is larger with slices of the full capacity
+    static const bool one_launch = getenv("TDA_FINISH_ONE_LAUNCH") != nullptr;
+    int k_lo = INT_MIN;
+    if (cap > 64 && !one_launch) {
+        const int nw = FIN_WAVES;
+        hipLaunchKernelGGL(diagram_finish_kernel, dim3((unsigned)((n_all + nw - 1) / nw)), dim3(64 * nw), (size_t)64 * 4 * 8 * nw, st, S,
+                           n_dgm, 64, k_lo);
+        k_lo = 64;
+    }
     int nw = FIN_WAVES;                                  // diagrams per workgroup: fewer when the slices are large
     while (nw > 1 && (size_t)cap * 4 * 8 * nw > 32 * 1024) nw >>= 1;
     const size_t lds = (size_t)cap * 4 * 8 * nw;
     if (lds > 48 * 1024)
         TDA_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(diagram_finish_kernel),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    const long long n_all = (long long)n_sets * n_dgm;
-    hipLaunchKernelGGL(diagram_finish_kernel, dim3((unsigned)((n_all + nw - 1) / nw)), dim3(64 * nw), lds, st, S, n_dgm, cap);
+    hipLaunchKernelGGL(diagram_finish_kernel, dim3((unsigned)((n_all + nw - 1) / nw)), dim3(64 * nw), lds, st, S, n_dgm, cap, k_lo);
     TDA_HIP(ctx, hipGetLastError());
     return TDA_OK;
 }
