@@ -21,13 +21,15 @@ for path in glob.glob(os.path.join(out, "pmc_cnt", "**", "*counter_collection.cs
         k = re.sub(r"\(.*$", "", r["Kernel_Name"]).replace("void ", "").strip()
         acc[k][r["Counter_Name"]] += float(r["Counter_Value"])
 lines = []
-for k, wpw in (("rips_cloud_kernel<512, 1, unsigned int, false", 8), ("eeg_window_kernel<3, false, 1, false", 4),
-               ("wasserstein_kernel<2", 1), ("wasserstein_kernel<4", 1), ("diagram_finish_kernel", 3)):
+# window pairs of the run = workgroups of the audio first pass (8 waves each); every kernel's counts are divided by it
+# (the finishing pass and the H1 Wasserstein distances take two launches each since round 3: their sums are what counts)
+n_pairs = next(c["SQ_WAVES"] / 8 for name, c in acc.items() if name.startswith("rips_cloud_kernel<512, 1, unsigned int, false") and c.get("SQ_WAVES"))
+for k in ("rips_cloud_kernel<512, 1, unsigned int, false", "eeg_window_kernel<3, false, 1, false", "wasserstein_kernel<2",
+          "wasserstein_kernel<1", "wasserstein_kernel<4", "diagram_finish_kernel", "rips_cloud_kernel<512, 1, unsigned long long, true"):
     for name, c in acc.items():
         if name.startswith(k) and c.get("SQ_WAVES"):
-            n = c["SQ_WAVES"] / wpw
-            lines.append(f"{name[:60]:60s} windows={int(n):7d} valu/win={c['SQ_INSTS_VALU']/n:9.1f} salu/win={c['SQ_INSTS_SALU']/n:9.1f} "
-                         f"lds/win={c['SQ_INSTS_LDS']/n:8.1f}")
+            lines.append(f"{name[:60]:60s} windows={int(n_pairs):7d} valu/win={c['SQ_INSTS_VALU']/n_pairs:9.1f} salu/win={c['SQ_INSTS_SALU']/n_pairs:9.1f} "
+                         f"lds/win={c['SQ_INSTS_LDS']/n_pairs:8.1f}")
 print("\n".join(lines))
 open(os.path.join(out, f"{tag}_inst_count.txt"), "w").write("\n".join(lines) + "\n")
 PY
