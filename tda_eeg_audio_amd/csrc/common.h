@@ -18,13 +18,17 @@ struct tda_ctx {
     unsigned long long* retry_ctr = nullptr;   // tda_set_retry_counter: device u64[4]
     unsigned long long* total_scratch = nullptr;   // class vectors of the last rung of the Rips ladders (rips.hip: TOT_SLOTS x 8.3 MB)
     int h1_order = 0;       // TDA_ORDER_*
-    // Lists of the windows a widening pass has to redo (rips.hip: retry_collect): TDA_RETRY_SLOTS buffers handed out in
-    // turn, one per Rips call, so that calls in flight on different streams (and the HIP graphs that captured them) do
-    // not share one.  [0] = entries, the window indices from [4] on.  Allocated with the context; a call with more
-    // windows than retry_cap replaces them all (the old ones stay alive for graphs that hold their addresses).
+    // Lists of the windows a widening pass has to redo (rips.hip: retry_collect): one buffer per STREAM -- the Rips calls
+    // of a stream, eager or replayed from a HIP graph captured on it, run one after the other, so a stream's list is never
+    // in use twice, while calls on different streams never share one.  TDA_RETRY_SLOTS buffers, allocated with the context
+    // and assigned to streams in the order they are first seen (more streams than buffers: the last one is shared and
+    // retry_shared counts it).  [0] = entries, [1] = workgroups done, the window indices from [4] on.  A call with more
+    // windows than retry_cap replaces all buffers (the old ones stay alive for graphs that hold their addresses).
     int* retry_buf[32] = {};
+    hipStream_t retry_stream[32] = {};
+    int retry_streams = 0;
+    int retry_shared = 0;
     int retry_cap = 0;
-    unsigned retry_next = 0;
     std::vector<void*> retired;
     // host-API staging workspace (grown on demand, only by the host-pointer twins)
     void* ws = nullptr;

@@ -2481,12 +2481,18 @@ tda_status retry_lists_reserve(tda_ctx* ctx, int n_win)
     ctx->retry_cap = cap;
     return TDA_OK;
 }
-// one list per Rips call, the slots in turn
-static tda_status retry_list_take(tda_ctx* ctx, int n_win, RipsOut& out)
+// the list of the stream the call is enqueued on (see tda_ctx::retry_buf)
+static tda_status retry_list_take(tda_ctx* ctx, int n_win, RipsOut& out, hipStream_t st)
 {
     const tda_status rc = retry_lists_reserve(ctx, n_win);
     if (rc != TDA_OK) return rc;
-    out.retry_list = ctx->retry_buf[ctx->retry_next++ % TDA_RETRY_SLOTS];
+    int i = 0;
+    while (i < ctx->retry_streams && ctx->retry_stream[i] != st) ++i;
+    if (i == ctx->retry_streams) {
+        if (i < TDA_RETRY_SLOTS) ctx->retry_stream[ctx->retry_streams++] = st;
+        else { i = TDA_RETRY_SLOTS - 1; ++ctx->retry_shared; }
+    }
+    out.retry_list = ctx->retry_buf[i];
     return TDA_OK;
 }
 // before every widening pass: which windows are flagged now
@@ -2609,7 +2615,7 @@ tda_status launch_rips_dm(tda_ctx* ctx, const double* dm, int n_win, int n, doub
     if (h0_cap < n) TDA_FAIL(ctx, TDA_ERR_INVALID, "h0_cap must be >= n");
     RipsOut out{h0, h0_cap, h0_cnt, h1, h1_cap, h1_cnt, status};
     const float th = (float)thresh;
-    tda_status rc = retry_list_take(ctx, n_win, out);
+    tda_status rc = retry_list_take(ctx, n_win, out, st);
     if (rc != TDA_OK) return rc;
     int W = ctx->words_dm < 1 ? 1 : ctx->words_dm;      // (32-bit class words exist in the fused EEG kernel only)
     // largest class capacity that still fits the 160 KiB LDS
@@ -2708,7 +2714,7 @@ static tda_status launch_eeg_source(tda_ctx* ctx, const WindowSource& src, int n
     if (n_t < 2 || n_t > CD_RES_CHUNKS * CD_TCH) TDA_FAIL(ctx, TDA_ERR_UNSUPPORTED, "the fused EEG kernel takes windows of 2..256 samples (the reference has 250)");
     if (h0_cap < n_ch) TDA_FAIL(ctx, TDA_ERR_INVALID, "h0_cap must be >= n_ch");
     RipsOut out{h0, h0_cap, h0_cnt, h1, h1_cap, h1_cnt, status};
-    { const tda_status rc0 = retry_list_take(ctx, n_win, out); if (rc0 != TDA_OK) return rc0; }
+    { const tda_status rc0 = retry_list_take(ctx, n_win, out, st); if (rc0 != TDA_OK) return rc0; }
     // The window is fetched twice (means, then centred products): 128 VGPRs, four workgroups per CU.  The second
     // fetch misses the 4 MB L2 of the XCD (128 windows in flight there) and shows in FETCH_SIZE (181 KB per window
     // against 95 KB algorithmic), but the windows in flight on the whole chip are 96 MB, inside the 256 MiB Infinity
@@ -2796,7 +2802,7 @@ tda_status launch_rips_cloud(tda_ctx* ctx, const double* src, const int* aux, in
     if (h0_cap < p_max) TDA_FAIL(ctx, TDA_ERR_INVALID, "h0_cap must be >= max points per cloud");
     RipsOut out{h0, h0_cap, h0_cnt, h1, h1_cap, h1_cnt, status};
     const float th = (float)thresh;
-    tda_status rc = retry_list_take(ctx, n_win, out);
+    tda_status rc = retry_list_take(ctx, n_win, out, st);
     if (rc != TDA_OK) return rc;
     // class capacity ladder: 32 bits (two workgroups per CU for 124-point clouds), then 64, then 128
     // while the table fits LDS; each wider pass only redoes the windows the previous one flagged
