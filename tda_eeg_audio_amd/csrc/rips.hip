@@ -2392,7 +2392,7 @@ __device__ __forceinline__ void eeg_one_window(unsigned char* smem, const Window
         double r = (accs[CdLayout<NB>::acc_index(i, j)] * fact / sdev[i]) / sdev[j];
         r = r > 1.0 ? 1.0 : r; r = r < -1.0 ? -1.0 : r; if (r != r) r = 0.0;       // clip; nan_to_num (nb2:95)
         if (r_out) *r_out = r;
-        double d = sqrt(2.0 * (1.0 - r));                                        // nb2:108
+        double d = sqrt_rn(2.0 * (1.0 - r));                                     // nb2:108 (sqrt() bit for bit: common.h)
         if (!(d > 0.0) || i == j) d = 0.0;                                       // nb2:119-120
         return d;
     };
