@@ -454,7 +454,7 @@ def features_leg(args, ctx, device, mine, shards, n_rec, rank, world, nb):
             "eeg_kernel_ms": eeg_kernel_ms, "eeg_kernel_windows": int(n_win)}
 
 
-def pcie_leg(ctx, device, eeg_b, aud_b, wpr, n_rec=256):
+def pcie_leg(ctx, device, eeg_b, aud_b, wpr, n_rec=1024):
     """PCIe-inclusive rate (never `value`): pinned host windows -> HBM -> the same step -> result rows back to the
     host, copies and kernels on one stream; a bounded sample of one band's batch.  (One stream on purpose: with the
     upload of the next batch on its own stream beside the step the copy drops from 57 to 42 GB/s and the leg from 0.47 to
